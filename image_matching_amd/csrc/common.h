@@ -1,0 +1,43 @@
+// Internal declarations shared by the HIP translation units of libimatch.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/imatch.h"
+
+struct imatch_ctx {
+    int device;
+    hipStream_t stream;
+    char err[512];
+    // growable device workspace, reused across calls so the hot path does not hipMalloc
+    void* ws;
+    size_t ws_bytes;
+    // pinned host staging
+    void* hs;
+    size_t hs_bytes;
+};
+
+struct imatch_features {
+    imatch_ctx* ctx;
+    int64_t n;        // valid rows
+    int64_t n_pad;    // rows allocated, multiple of IMATCH_ROW_PAD; pad rows are zero with norm +inf
+    uint16_t* desc;   // bf16 [n_pad][128], device
+    float* norm;      // f32 [n_pad] squared L2 norms (exact integers for integral sets), device
+    int* flag;        // device int: 1 if some value was not an integer in 0..255
+    int integral;     // host copy of !flag, valid after creation
+};
+
+#define IMATCH_ROW_PAD 1024
+
+int imatch_set_err(imatch_ctx* ctx, int code, const char* fmt, ...);
+int imatch_ws_reserve(imatch_ctx* ctx, size_t bytes);
+int imatch_hs_reserve(imatch_ctx* ctx, size_t bytes);
+
+#define HIP_TRY(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return imatch_set_err((ctx), IMATCH_EHIP, "%s: %s (%s:%d)", #call,          \
+                                  hipGetErrorString(e_), __FILE__, __LINE__);           \
+    } while (0)

@@ -1,0 +1,484 @@
+// Brute-force kNN (k = 2) on bf16 MFMA with the top-2 selection fused into the epilogue.
+// Replaces cv2.BFMatcher(NORM_L2).knnMatch(k=2) and the ratio loop of
+// match_finder.find_matches (reference match_finder.py:177-197).
+//
+// Formulation: ssd(q,t) = |q|^2 + |t|^2 - 2 q.t. For integer descriptors 0..255 every product
+// and every 128-term sum is an integer below 2^24, so the bf16 MFMA with f32 accumulate is
+// exact, and so is v = |t|^2 - 2 q.t computed with one f32 fma. |q|^2 is added in the merge.
+//
+// Tiling (wave64, v_mfma_f32_32x32x16_bf16): the TRAIN rows are the A operand (rows of the
+// 32x32 result sit in the 16 accumulator registers), the QUERIES are the B operand (columns
+// sit on the lanes). Each lane therefore owns one query per 32-query block and can keep that
+// query's running top-2 in its own registers. A wave holds the B fragments of 32*QB queries
+// in registers for the whole kernel; train rows stream HBM -> LDS (global_load_lds, 16 B per
+// lane, XOR-swizzled through the source address) and are read as A fragments by ds_read_b128.
+// The epilogue costs one fma and one compare per result: only results below the query's
+// current second-best take the (wave-uniform, rare) insertion path.
+#include "common.h"
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define TN 64                        // train rows per LDS stage
+#define STAGE_U4 (TN * 16 + TN / 4)  // uint4 per stage: TN rows x 256 B, then TN f32 norms
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+template <int NW, int QB>
+__global__ void __launch_bounds__(NW * 64, 2)
+knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ tnorm,
+            int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi) {
+    __shared__ uint4 lds[2 * STAGE_U4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // blocks b and b+8 share an XCD (its L2): give them the same train chunk, different query tiles
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int chunk = (j / nQt) * 8 + xcd;
+    const int qt = j % nQt;
+    if (chunk >= nChunks) return;
+    const int s_begin = (int)((int64_t)nStages * chunk / nChunks);
+    const int s_end = (int)((int64_t)nStages * (chunk + 1) / nChunks);
+
+    // resident query fragments: lane holds q[row r][k = 16 ks + 8 h .. +7] = 16-byte chunk 2 ks + h
+    const int64_t qrow0 = (int64_t)qt * (NW * 32 * QB) + wave * (32 * QB);
+    bf16x8 qf[QB][8];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            uint4 u = Qd[(qrow0 + qb * 32 + r) * 16 + 2 * ks + h];
+            qf[qb][ks] = __builtin_bit_cast(bf16x8, u);
+        }
+
+    float b1[QB], b2[QB];
+    int i1[QB], i2[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        b1[qb] = FLT_MAX; b2[qb] = FLT_MAX; i1[qb] = -1; i2[qb] = -1;
+    }
+
+    // stage loader: slot = 16-byte piece of the stage image; LDS is lane-linear, the swizzle
+    // chunk' = chunk ^ (row & 15) is applied to the per-lane source address
+    auto stage = [&](int s, int buf) {
+        const uint4* src = Td + (int64_t)s * TN * 16;
+#pragma unroll
+        for (int i = 0; i < (TN * 16) / (NW * 64); ++i) {
+            const int slot = i * NW * 64 + wave * 64 + lane;
+            const int row = slot >> 4, cp = slot & 15;
+            const uint4* g = src + row * 16 + (cp ^ (row & 15));
+            uint4* l = lds + buf * STAGE_U4 + i * NW * 64 + wave * 64;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)l, 16, 0, 0);
+        }
+        if (wave == 0) {
+            const float* g = tnorm + (int64_t)s * TN + lane;
+            uint4* l = lds + buf * STAGE_U4 + TN * 16;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)l, 4, 0, 0);
+        }
+    };
+
+    if (s_begin < s_end) stage(s_begin, 0);
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < s_end) stage(s + 1, buf ^ 1);
+
+        const uint4* img = lds + buf * STAGE_U4;
+#pragma unroll
+        for (int tile = 0; tile < TN / 32; ++tile) {
+            bf16x8 af[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                uint4 u = img[(tile * 32 + r) * 16 + ((2 * ks + h) ^ (r & 15))];
+                af[ks] = __builtin_bit_cast(bf16x8, u);
+            }
+            // norms of the 16 train rows this lane sees: row(reg) = (reg&3) + 8*(reg>>2) + 4*h
+            float tnr[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint4 u = img[TN * 16 + tile * 8 + 2 * g + h];
+                tnr[4 * g + 0] = __uint_as_float(u.x);
+                tnr[4 * g + 1] = __uint_as_float(u.y);
+                tnr[4 * g + 2] = __uint_as_float(u.z);
+                tnr[4 * g + 3] = __uint_as_float(u.w);
+            }
+            const int rowbase = s * TN + tile * 32 + 4 * h;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                f32x16 acc = {0};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], qf[qb][ks], acc, 0, 0, 0);
+                float v[16];
+                const float thr = b2[qb];
+                bool hit = false;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    v[reg] = fmaf(acc[reg], -2.0f, tnr[reg]);
+                    hit |= v[reg] < thr;
+                }
+                if (__builtin_amdgcn_ballot_w64(hit)) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        if (__builtin_amdgcn_ballot_w64(v[reg] < b2[qb])) {
+                            const int idx = rowbase + (reg & 3) + 8 * (reg >> 2);
+                            const float x = v[reg];
+                            if (x < b1[qb]) {
+                                b2[qb] = b1[qb]; i2[qb] = i1[qb]; b1[qb] = x; i1[qb] = idx;
+                            } else if (x < b2[qb]) {
+                                b2[qb] = x; i2[qb] = idx;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // one partial list per (chunk, lane half)
+    const int64_t list = (int64_t)chunk * 2 + h;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int64_t o = list * Qpad + qrow0 + qb * 32 + r;
+        pb[o] = make_float2(b1[qb], b2[qb]);
+        pi[o] = make_int2(i1[qb], i2[qb]);
+    }
+}
+
+__device__ inline void top2_insert(int& s1, int& j1, int& s2, int& j2, int s, int j) {
+    if (s < s1 || (s == s1 && j < j1)) {
+        s2 = s1; j2 = j1; s1 = s; j1 = j;
+    } else if (s < s2 || (s == s2 && j < j2)) {
+        s2 = s; j2 = j;
+    }
+}
+
+// merges the partial lists of one query, adds |q|^2, writes (ssd1, idx1, ssd2, idx2)
+__global__ void knn2_finish_kernel(const float2* __restrict__ pb, const int2* __restrict__ pi, int nLists,
+                                   int64_t Qpad, const float* __restrict__ qnorm, int64_t nq, int64_t nt,
+                                   int idx_offset, int4* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int s1 = INT_MAX, s2 = INT_MAX, j1 = INT_MAX, j2 = INT_MAX;
+    for (int l = 0; l < nLists; ++l) {
+        const float2 b = pb[(int64_t)l * Qpad + q];
+        const int2 i = pi[(int64_t)l * Qpad + q];
+        if (i.x >= 0 && i.x < nt) top2_insert(s1, j1, s2, j2, (int)b.x, i.x);
+        if (i.y >= 0 && i.y < nt) top2_insert(s1, j1, s2, j2, (int)b.y, i.y);
+    }
+    const int qn = (int)qnorm[q];
+    int4 o;
+    o.x = (j1 == INT_MAX) ? INT_MAX : s1 + qn;
+    o.y = (j1 == INT_MAX) ? -1 : j1 + idx_offset;
+    o.z = (j2 == INT_MAX) ? INT_MAX : s2 + qn;
+    o.w = (j2 == INT_MAX) ? -1 : j2 + idx_offset;
+    out[q] = o;
+}
+
+__global__ void merge_top2_kernel(const int4* __restrict__ in, int nLists, int64_t nq, int4* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int s1 = INT_MAX, s2 = INT_MAX, j1 = INT_MAX, j2 = INT_MAX;
+    for (int l = 0; l < nLists; ++l) {
+        const int4 e = in[(int64_t)l * nq + q];
+        if (e.y >= 0) top2_insert(s1, j1, s2, j2, e.x, e.y);
+        if (e.w >= 0) top2_insert(s1, j1, s2, j2, e.z, e.w);
+    }
+    int4 o;
+    o.x = (j1 == INT_MAX) ? INT_MAX : s1;
+    o.y = (j1 == INT_MAX) ? -1 : j1;
+    o.z = (j2 == INT_MAX) ? INT_MAX : s2;
+    o.w = (j2 == INT_MAX) ? -1 : j2;
+    out[q] = o;
+}
+
+// Lowe ratio test with the reference's float semantics (match_finder.py:193): the f32-rounded
+// distances are widened to double, the product is a double. Survivors are compacted in query
+// order by one workgroup (a block-wide exclusive scan per 1024 queries).
+__global__ void __launch_bounds__(1024)
+ratio_kernel(const int4* __restrict__ in, int64_t nq, double ratio, int* __restrict__ gq, int* __restrict__ gt,
+             float* __restrict__ gd, unsigned long long* __restrict__ n_good) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int64_t q0 = 0; q0 < nq; q0 += 1024) {
+        const int64_t q = q0 + threadIdx.x;
+        bool good = false;
+        int4 e = make_int4(0, -1, 0, -1);
+        float d1 = 0.f;
+        if (q < nq) {
+            e = in[q];
+            if (e.y >= 0 && e.w >= 0) {
+                d1 = sqrtf((float)e.x);
+                const float d2 = sqrtf((float)e.z);
+                good = (double)d1 < ratio * (double)d2;
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(good);
+        const int within = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (good) {
+            gq[off + within] = (int)q;
+            gt[off + within] = e.y;
+            gd[off + within] = d1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wsum[w];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_good = (unsigned long long)base_s;
+}
+
+// ---- descriptor upload: u8 / f32 -> bf16 rows + squared norms ------------------------------
+// one wave per row; lane handles 2 values
+template <typename T>
+__global__ void pack_rows_kernel(const T* __restrict__ src, int64_t n, int64_t n_pad, uint16_t* __restrict__ dst,
+                                 float* __restrict__ norm, int* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_pad) return;
+    float a = 0.f, b = 0.f;
+    bool bad = false;
+    if (row < n) {
+        a = (float)src[row * 128 + 2 * lane];
+        b = (float)src[row * 128 + 2 * lane + 1];
+        bad = !(a >= 0.f && a <= 255.f && a == truncf(a)) || !(b >= 0.f && b <= 255.f && b == truncf(b));
+    }
+    const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+    const float ra = (float)ha, rb = (float)hb;
+    uint32_t packed = (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+    ((uint32_t*)dst)[row * 64 + lane] = packed;
+    float s = ra * ra + rb * rb;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) norm[row] = (row < n) ? s : INFINITY;
+    if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(flag, 1);
+}
+
+static int features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out) {
+    imatch_features* f = (imatch_features*)calloc(1, sizeof(imatch_features));
+    if (!f) return imatch_set_err(ctx, IMATCH_ENOMEM, "host alloc");
+    f->ctx = ctx;
+    f->n = n;
+    f->n_pad = ((n + IMATCH_ROW_PAD - 1) / IMATCH_ROW_PAD) * IMATCH_ROW_PAD;
+    if (f->n_pad == 0) f->n_pad = IMATCH_ROW_PAD;
+    if (hipMalloc((void**)&f->desc, (size_t)f->n_pad * 256) != hipSuccess ||
+        hipMalloc((void**)&f->norm, (size_t)f->n_pad * 4) != hipSuccess ||
+        hipMalloc((void**)&f->flag, 256) != hipSuccess) {
+        if (f->desc) (void)hipFree(f->desc);
+        if (f->norm) (void)hipFree(f->norm);
+        free(f);
+        return imatch_set_err(ctx, IMATCH_ENOMEM, "device alloc for %lld descriptors", (long long)n);
+    }
+    *out = f;
+    return IMATCH_OK;
+}
+
+template <typename T>
+static int features_pack(imatch_ctx* ctx, imatch_features* f, const T* src_dev) {
+    HIP_TRY(ctx, hipMemsetAsync(f->flag, 0, 256, ctx->stream));
+    const int rows_per_block = 4;
+    const unsigned grid = (unsigned)((f->n_pad + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(pack_rows_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, src_dev, f->n, f->n_pad, f->desc,
+                       f->norm, f->flag);
+    HIP_TRY(ctx, hipGetLastError());
+    int flag = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&flag, f->flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    f->integral = !flag;
+    return IMATCH_OK;
+}
+
+template <typename T>
+static int features_from_host(imatch_ctx* ctx, const T* desc, int64_t n, int d, imatch_features** out) {
+    if (!ctx || !out || n < 0 || (n > 0 && !desc)) return imatch_set_err(ctx, IMATCH_EINVAL, "null or negative argument");
+    if (d != IMATCH_DESC_DIM) return imatch_set_err(ctx, IMATCH_EINVAL, "descriptor dimension %d, need 128", d);
+    if (n > (int64_t)INT_MAX - 2 * IMATCH_ROW_PAD) return imatch_set_err(ctx, IMATCH_ESIZE, "too many descriptors");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    imatch_features* f = nullptr;
+    int rc = features_alloc(ctx, n, &f);
+    if (rc) return rc;
+    const size_t bytes = (size_t)n * 128 * sizeof(T);
+    rc = imatch_ws_reserve(ctx, bytes ? bytes : 16);
+    if (rc) { imatch_features_free(f); return rc; }
+    if (bytes) {
+        hipError_t e = hipMemcpyAsync(ctx->ws, desc, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { imatch_features_free(f); return imatch_set_err(ctx, IMATCH_EHIP, "upload: %s", hipGetErrorString(e)); }
+    }
+    rc = features_pack<T>(ctx, f, (const T*)ctx->ws);
+    if (rc) { imatch_features_free(f); return rc; }
+    *out = f;
+    return IMATCH_OK;
+}
+
+// ---- launch -------------------------------------------------------------------------------
+template <int NW, int QB>
+static void launch_knn(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int nQt, int nChunks,
+                       int nStages, int64_t Qpad, float2* pb, int2* pi) {
+    const unsigned grid = (unsigned)(nQt * nChunks);
+    hipLaunchKernelGGL((knn2_kernel<NW, QB>), dim3(grid), dim3(NW * 64), 0, ctx->stream, (const uint4*)q->desc,
+                       (const uint4*)t->desc, t->norm, nQt, nChunks, nStages, Qpad, pb, pi);
+}
+
+static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t idx_offset,
+                    int32_t* out4_dev) {
+    if (!ctx || !q || !t || !out4_dev) return imatch_set_err(ctx, IMATCH_EINVAL, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (q->n == 0) return IMATCH_OK;
+    // query tile per workgroup: 4 waves x 32*QB queries
+    int QB = 4;
+    if (q->n <= 128) QB = 1;
+    else if (q->n <= 1024) QB = 2;
+    const int qtile = 4 * 32 * QB;
+    const int64_t Qpad = q->n_pad;  // multiple of 1024, so of every qtile
+    const int nQt = (int)((q->n + qtile - 1) / qtile);
+    const int nStages = (int)(t->n_pad / TN);
+    // chunks: a multiple of 8 (one group per XCD), enough workgroups for ~4 per CU slot, at least 4 stages each
+    int nChunks = (2048 + nQt - 1) / nQt;
+    if (nChunks > nStages / 4) nChunks = nStages / 4;
+    nChunks = (nChunks / 8) * 8;
+    if (nChunks < 8) nChunks = 8;
+    const int64_t nLists = (int64_t)nChunks * 2;
+    const size_t pbytes = (size_t)nLists * Qpad * 8;
+    int rc = imatch_ws_reserve(ctx, 2 * pbytes);
+    if (rc) return rc;
+    float2* pb = (float2*)ctx->ws;
+    int2* pi = (int2*)((char*)ctx->ws + pbytes);
+    if (QB == 4) launch_knn<4, 4>(ctx, q, t, nQt, nChunks, nStages, Qpad, pb, pi);
+    else if (QB == 2) launch_knn<4, 2>(ctx, q, t, nQt, nChunks, nStages, Qpad, pb, pi);
+    else launch_knn<4, 1>(ctx, q, t, nQt, nChunks, nStages, Qpad, pb, pi);
+    HIP_TRY(ctx, hipGetLastError());
+    // rows of query tiles beyond nQt are never written by the main kernel but are >= q->n: not read
+    hipLaunchKernelGGL(knn2_finish_kernel, dim3((unsigned)((q->n + 255) / 256)), dim3(256), 0, ctx->stream, pb, pi,
+                       (int)nLists, Qpad, q->norm, q->n, t->n, idx_offset, (int4*)out4_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return IMATCH_OK;
+}
+
+extern "C" {
+
+int imatch_features_from_host_f32(imatch_ctx* ctx, const float* desc, int64_t n, int d, imatch_features** out) {
+    return features_from_host<float>(ctx, desc, n, d, out);
+}
+
+int imatch_features_from_host_u8(imatch_ctx* ctx, const uint8_t* desc, int64_t n, int d, imatch_features** out) {
+    return features_from_host<uint8_t>(ctx, desc, n, d, out);
+}
+
+int imatch_features_from_device_u8(imatch_ctx* ctx, const uint8_t* desc_dev, int64_t n, int d, imatch_features** out) {
+    if (!ctx || !out || n < 0 || (n > 0 && !desc_dev)) return imatch_set_err(ctx, IMATCH_EINVAL, "null or negative argument");
+    if (d != IMATCH_DESC_DIM) return imatch_set_err(ctx, IMATCH_EINVAL, "descriptor dimension %d, need 128", d);
+    if (n > (int64_t)INT_MAX - 2 * IMATCH_ROW_PAD) return imatch_set_err(ctx, IMATCH_ESIZE, "too many descriptors");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    imatch_features* f = nullptr;
+    int rc = features_alloc(ctx, n, &f);
+    if (rc) return rc;
+    rc = features_pack<uint8_t>(ctx, f, desc_dev);
+    if (rc) { imatch_features_free(f); return rc; }
+    *out = f;
+    return IMATCH_OK;
+}
+
+int64_t imatch_features_count(const imatch_features* f) { return f ? f->n : 0; }
+
+int imatch_features_is_integral(const imatch_features* f) { return f ? f->integral : 0; }
+
+void imatch_features_free(imatch_features* f) {
+    if (!f) return;
+    if (f->ctx) {
+        (void)hipSetDevice(f->ctx->device);
+        (void)hipStreamSynchronize(f->ctx->stream);
+    }
+    if (f->desc) (void)hipFree(f->desc);
+    if (f->norm) (void)hipFree(f->norm);
+    if (f->flag) (void)hipFree(f->flag);
+    free(f);
+}
+
+int imatch_knn2_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t idx_offset,
+                    int32_t* out4_dev) {
+    return knn2_run(ctx, q, t, idx_offset, out4_dev);
+}
+
+int imatch_knn2(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t* idx, float* dist) {
+    if (!ctx || !q || !t || (q->n > 0 && (!idx || !dist))) return imatch_set_err(ctx, IMATCH_EINVAL, "null argument");
+    if (q->n == 0) return IMATCH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int4* out_dev = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&out_dev, (size_t)q->n * 16));
+    int rc = knn2_run(ctx, q, t, 0, (int32_t*)out_dev);
+    if (rc == IMATCH_OK) rc = imatch_hs_reserve(ctx, (size_t)q->n * 16);
+    if (rc == IMATCH_OK) {
+        hipError_t e = hipMemcpyAsync(ctx->hs, out_dev, (size_t)q->n * 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = imatch_set_err(ctx, IMATCH_EHIP, "knn2 download: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(out_dev);
+    if (rc) return rc;
+    const int32_t* o = (const int32_t*)ctx->hs;
+    for (int64_t i = 0; i < q->n; ++i) {
+        idx[2 * i] = o[4 * i + 1];
+        idx[2 * i + 1] = o[4 * i + 3];
+        dist[2 * i] = o[4 * i + 1] >= 0 ? sqrtf((float)o[4 * i]) : INFINITY;
+        dist[2 * i + 1] = o[4 * i + 3] >= 0 ? sqrtf((float)o[4 * i + 2]) : INFINITY;
+    }
+    return IMATCH_OK;
+}
+
+int imatch_merge_top2_dev(imatch_ctx* ctx, const int32_t* in4_dev, int n_lists, int64_t nq, int32_t* out4_dev) {
+    if (!ctx || !in4_dev || !out4_dev || n_lists < 1 || nq < 0) return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    if (nq == 0) return IMATCH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(merge_top2_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const int4*)in4_dev, n_lists, nq, (int4*)out4_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return IMATCH_OK;
+}
+
+int imatch_ratio_dev(imatch_ctx* ctx, const int32_t* out4_dev, int64_t nq, double ratio, int32_t* good_q,
+                     int32_t* good_t, float* good_d, int64_t* n_good) {
+    if (!ctx || !n_good || nq < 0 || (nq > 0 && (!out4_dev || !good_q || !good_t || !good_d)))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    *n_good = 0;
+    if (nq == 0) return IMATCH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // workspace: gq, gt, gd (nq each) + counter; placed after any knn partials are consumed (same stream)
+    const size_t arr = ((size_t)nq * 4 + 255) & ~(size_t)255;
+    char* dev = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&dev, 3 * arr + 256));
+    int rc = imatch_hs_reserve(ctx, 3 * arr + 256);
+    if (rc) { (void)hipFree(dev); return rc; }
+    hipLaunchKernelGGL(ratio_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int4*)out4_dev, nq, ratio, (int*)dev,
+                       (int*)(dev + arr), (float*)(dev + 2 * arr), (unsigned long long*)(dev + 3 * arr));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->hs, dev, 3 * arr + 256, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return imatch_set_err(ctx, IMATCH_EHIP, "ratio: %s", hipGetErrorString(e));
+    const char* hsrc = (const char*)ctx->hs;
+    const int64_t g = (int64_t)*(const unsigned long long*)(hsrc + 3 * arr);
+    memcpy(good_q, hsrc, (size_t)g * 4);
+    memcpy(good_t, hsrc + arr, (size_t)g * 4);
+    memcpy(good_d, hsrc + 2 * arr, (size_t)g * 4);
+    *n_good = g;
+    return IMATCH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+/*
+ * imatch.h -- C-ABI of libimatch.so, the MI355X (gfx950) implementation of the
+ * SIFT extract -> kNN(k=2)+ratio -> homography hot path of Fricodelco/image_matching.
+ *
+ * The reference has no FFI: its seam is the Python class `match_finder`
+ * (image_processing/src/image_processing/match_finder.py:26-352, "MF" below).
+ * Each entry point here is what a ctypes binding inside that class calls in
+ * place of one cv2 call; the citation names the cv2 call site it replaces.
+ *
+ * Conventions: plain pointers and sizes only; every function returns
+ * IMATCH_OK (0) or a negative IMATCH_E* code and never aborts;
+ * imatch_last_error(ctx) gives the message. A context owns one HIP device and
+ * one stream; calls on one context must be serialised by the caller (the Python
+ * wrapper holds a lock per context). Host pointers unless a name says `_dev`.
+ */
+#ifndef IMATCH_H
+#define IMATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMATCH_OK       0
+#define IMATCH_EINVAL  (-1)  /* bad argument (null pointer, negative size, wrong dimension) */
+#define IMATCH_EHIP    (-2)  /* a HIP runtime call failed; message holds hipGetErrorString */
+#define IMATCH_ENOMEM  (-3)  /* device or host allocation failed */
+#define IMATCH_ESIZE   (-4)  /* size beyond what the kernels support */
+
+#define IMATCH_DESC_DIM 128  /* SIFT descriptor length; the only dimension the MFMA kernel takes */
+
+typedef struct imatch_ctx imatch_ctx;
+typedef struct imatch_features imatch_features;
+
+/* Library / context ------------------------------------------------------- */
+
+/* Replaces the capability probe match_finder.is_cuda_cv (MF:341-352): number of HIP devices, or <0. */
+int imatch_device_count(void);
+/* Replaces the per-call cv2.cuda_Stream()/matcher construction (MF:185-186): one device + one stream. */
+int imatch_init(int device, imatch_ctx** out);
+void imatch_destroy(imatch_ctx* ctx);
+const char* imatch_last_error(const imatch_ctx* ctx);
+/* The HIP stream of the context as a void* (hipStream_t), for callers that time with events. */
+void* imatch_stream(imatch_ctx* ctx);
+int imatch_synchronize(imatch_ctx* ctx);
+
+/* Descriptor sets resident in HBM ----------------------------------------- */
+/* Replaces cv2.cuda_GpuMat(descriptors) (MF:187-188), but the set outlives the call:
+ * rows are stored as bf16 [n_pad][128] (exact for 0..255 integers) plus f32 squared norms. */
+int imatch_features_from_host_f32(imatch_ctx* ctx, const float* desc, int64_t n, int d, imatch_features** out);
+int imatch_features_from_host_u8(imatch_ctx* ctx, const uint8_t* desc, int64_t n, int d, imatch_features** out);
+/* Same, from a u8 [n][128] matrix already in device memory (a torch tensor's data_ptr). */
+int imatch_features_from_device_u8(imatch_ctx* ctx, const uint8_t* desc_dev, int64_t n, int d, imatch_features** out);
+int64_t imatch_features_count(const imatch_features* f);
+/* 1 when every descriptor value of the set is an integer in 0..255 (kNN is then bit-exact), else 0. */
+int imatch_features_is_integral(const imatch_features* f);
+void imatch_features_free(imatch_features* f);
+
+/* Brute-force kNN, k = 2 --------------------------------------------------- */
+/* Replaces cv2.BFMatcher(cv2.NORM_L2).knnMatch(q, t, k=2) (MF:182-183) and the cv2.cuda
+ * matcher (MF:185-189). idx/dist are [Q][2]; a missing neighbour (N < 2) has idx -1, dist +inf.
+ * dist = sqrtf((float)ssd) with ssd the exact integer sum of squared differences; ties go to
+ * the lower train index, as OpenCV's ascending strict-< scan. */
+int imatch_knn2(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t,
+                int32_t* idx, float* dist);
+/* Device-side form used by the bench and the multi-GPU path: writes int32 [Q][4] =
+ * (ssd1, idx1 + idx_offset, ssd2, idx2 + idx_offset) to device memory, asynchronously on the
+ * context's stream; a missing neighbour is (INT32_MAX, -1). */
+int imatch_knn2_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t,
+                    int32_t idx_offset, int32_t* out4_dev);
+/* Merge step after the all-gather of per-shard top-2 (no reference counterpart: the reference is
+ * single-process). in4_dev is int32 [n_lists][Q][4]; picks the two smallest by
+ * (ssd, idx) lexicographic order into out4_dev [Q][4]. */
+int imatch_merge_top2_dev(imatch_ctx* ctx, const int32_t* in4_dev, int n_lists, int64_t nq,
+                          int32_t* out4_dev);
+/* Replaces the Python ratio loop `m.distance < points_quality * n.distance` (MF:191-194):
+ * evaluates double(f32 d1) < ratio * double(f32 d2) per query on out4 (device), compacts the
+ * survivors in query order. good_q/good_t/good_d are host arrays of capacity nq. */
+int imatch_ratio_dev(imatch_ctx* ctx, const int32_t* out4_dev, int64_t nq, double ratio,
+                     int32_t* good_q, int32_t* good_t, float* good_d, int64_t* n_good);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMATCH_H */

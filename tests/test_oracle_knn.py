@@ -1,0 +1,63 @@
+"""CPU: the kNN/ratio oracle against an independent numpy statement of Spec M and the golden fixture."""
+import os
+
+import numpy as np
+
+import oracle
+from image_matching_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _numpy_knn2(q, t):
+    q = q.astype(np.int64)
+    t = t.astype(np.int64)
+    ssd = ((q[:, None, :] - t[None, :, :]) ** 2).sum(-1)
+    order = np.argsort(ssd, axis=1, kind="stable")[:, :2]  # stable: lower index first on ties
+    d = np.sqrt(np.take_along_axis(ssd, order, 1).astype(np.float32))
+    return order.astype(np.int32), d
+
+
+def test_knn2_matches_numpy_with_ties():
+    t = synth.synth_descriptors(600, seed=3)
+    q, src, dup = synth.synth_queries(t, 64, seed=4, dup_frac=0.25)
+    assert (dup >= 0).sum() > 4
+    idx, dist = oracle.knn2(q, t)
+    ridx, rdist = _numpy_knn2(q, t)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist, rdist)
+    for i in np.nonzero(dup >= 0)[0]:
+        assert idx[i, 0] == src[i] and idx[i, 1] == dup[i] and dist[i, 0] == 0 and dist[i, 1] == 0
+    # float32 storage gives the same answer as u8 storage
+    idx2, dist2 = oracle.knn2(q.astype(np.float32), t.astype(np.float32))
+    assert np.array_equal(idx, idx2) and np.array_equal(dist, dist2)
+
+
+def test_knn2_degenerate_rows():
+    q = synth.synth_descriptors(5, seed=1)
+    idx, dist = oracle.knn2(q, q[:1])
+    assert (idx[:, 0] == 0).all() and (idx[:, 1] == -1).all() and np.isinf(dist[:, 1]).all()
+    idx, dist = oracle.knn2(q, q[:0])
+    assert (idx == -1).all() and np.isinf(dist).all()
+    idx, dist = oracle.knn2(q[:0], q)
+    assert idx.shape == (0, 2)
+
+
+def test_ratio_float_semantics():
+    # d1 < r*d2 is evaluated in double on f32-rounded distances (match_finder.py:193)
+    idx = np.array([[0, 1], [2, 3], [4, -1], [5, 6]], np.int32)
+    d2 = np.float32(10.0)
+    just_below = np.nextafter(np.float32(7.0), np.float32(0))
+    dist = np.array([[7.0, d2], [just_below, d2], [1.0, np.inf], [0.0, 0.0]], np.float32)
+    gq, gt, gd = oracle.ratio(idx, dist, 0.7)
+    want = [i for i in range(4) if idx[i, 1] >= 0 and float(dist[i, 0]) < 0.7 * float(dist[i, 1])]
+    assert want == [1]  # 0.7 * 10.0 rounds to exactly 7.0 in double: row 0 fails, the next float below passes
+    assert gq.tolist() == want and gt.tolist() == [2]
+
+
+def test_golden_knn_fixture():
+    g = np.load(os.path.join(GOLD, "knn_q256_n4096.npz"))
+    idx, dist = oracle.knn2(g["q"], g["t"])
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(dist, g["dist"])
+    gq, gt, gd = oracle.ratio(idx, dist, 0.7)
+    assert np.array_equal(gq, g["good_q"]) and np.array_equal(gt, g["good_t"])
