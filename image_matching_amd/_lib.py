@@ -21,6 +21,19 @@ class ImatchError(RuntimeError):
     pass
 
 
+class SiftParams(ctypes.Structure):
+    """imatch_sift_params (include/imatch.h); defaults = OpenCV's SIFT_create defaults + the
+    reference's CLAHE(30, (8,8)) (match_finder.py:200)."""
+    _fields_ = [("n_octave_layers", ctypes.c_int), ("contrast_threshold", ctypes.c_double),
+                ("edge_threshold", ctypes.c_double), ("sigma", ctypes.c_double), ("clahe", ctypes.c_int),
+                ("clahe_clip", ctypes.c_double), ("clahe_tiles_x", ctypes.c_int), ("clahe_tiles_y", ctypes.c_int)]
+
+    def __init__(self, n_octave_layers=3, contrast_threshold=0.04, edge_threshold=10.0, sigma=1.6, clahe=True,
+                 clahe_clip=30.0, clahe_tiles=(8, 8)):
+        super().__init__(int(n_octave_layers), float(contrast_threshold), float(edge_threshold), float(sigma),
+                         1 if clahe else 0, float(clahe_clip), int(clahe_tiles[0]), int(clahe_tiles[1]))
+
+
 # name -> (restype, argtypes); every symbol include/imatch.h declares
 SIGNATURES = {
     "imatch_device_count": (ctypes.c_int, []),
@@ -29,12 +42,25 @@ SIGNATURES = {
     "imatch_last_error": (ctypes.c_char_p, [c_vp]),
     "imatch_stream": (c_vp, [c_vp]),
     "imatch_synchronize": (ctypes.c_int, [c_vp]),
+    "imatch_set_profiling": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "imatch_knn2_kernel_ms": (ctypes.c_int, [c_vp, c_f32p]),
     "imatch_features_from_host_f32": (ctypes.c_int, [c_vp, c_f32p, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_features_from_host_u8": (ctypes.c_int, [c_vp, c_u8p, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_features_from_device_u8": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_features_count": (c_i64, [c_vp]),
     "imatch_features_is_integral": (ctypes.c_int, [c_vp]),
     "imatch_features_free": (None, [c_vp]),
+    "imatch_clahe": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                    ctypes.c_int, ctypes.c_int, c_u8p]),
+    "imatch_resize_area": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_u8p,
+                                          ctypes.c_int, ctypes.c_int]),
+    "imatch_sift_extract": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(SiftParams), ctypes.POINTER(c_vp)]),
+    "imatch_features_download": (ctypes.c_int, [c_vp, c_f32p, c_f32p]),
+    "imatch_features_image": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int]),
+    "imatch_sift_debug_layer": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
+                                               ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "imatch_sift_debug_octaves": (ctypes.c_int, [c_vp]),
     "imatch_knn2": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32p, c_f32p]),
     "imatch_knn2_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
     "imatch_merge_top2_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, c_vp]),
@@ -89,6 +115,21 @@ class Features:
     def integral(self):
         return bool(self.ctx.lib.imatch_features_is_integral(self._h))
 
+    def download(self, keypoints=True, descriptors=True):
+        """-> (kp float32 [K,7] = x, y, size, angle, response, octave, class_id; desc float32 [K,128])."""
+        kp = np.empty((self.n, 7), np.float32) if keypoints else None
+        desc = np.empty((self.n, 128), np.float32) if descriptors else None
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.imatch_features_download(
+                self._h, _ptr(kp, c_f32p) if keypoints else None, _ptr(desc, c_f32p) if descriptors else None))
+        return kp, desc
+
+    def image(self, h, w):
+        out = np.empty((h, w), np.uint8)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.imatch_features_image(self._h, _ptr(out, c_u8p), h, w))
+        return out
+
     def free(self):
         if self._h is not None and self.ctx._h is not None:
             self.ctx.lib.imatch_features_free(self._h)
@@ -140,6 +181,16 @@ class Context:
         with self.lock:
             self._check(self.lib.imatch_synchronize(self._h))
 
+    def set_profiling(self, on=True):
+        with self.lock:
+            self._check(self.lib.imatch_set_profiling(self._h, 1 if on else 0))
+
+    def knn2_kernel_ms(self):
+        ms = ctypes.c_float(0)
+        with self.lock:
+            self._check(self.lib.imatch_knn2_kernel_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
     # -- descriptor sets ----------------------------------------------------------------
     def features(self, desc):
         """Upload a [n,128] float32 or uint8 descriptor matrix."""
@@ -166,6 +217,57 @@ class Context:
             self._check(self.lib.imatch_features_from_device_u8(self._h, c_vp(dev_ptr), int(n), int(d),
                                                                 ctypes.byref(h)))
         return Features(self, h, n)
+
+    # -- pre-processing and SIFT ----------------------------------------------------------
+    @staticmethod
+    def _gray(img):
+        img = np.asarray(img)
+        if img.ndim != 2 or img.dtype != np.uint8:
+            raise ValueError("expected a 2-D uint8 image, got %s %s" % (img.dtype, img.shape))
+        if img.strides[1] != 1 or img.strides[0] < img.shape[1]:
+            img = np.ascontiguousarray(img)
+        return img
+
+    def clahe(self, img, clip_limit=30.0, tiles=(8, 8)):
+        img = self._gray(img)
+        out = np.empty(img.shape, np.uint8)
+        with self.lock:
+            self._check(self.lib.imatch_clahe(self._h, _ptr(img, c_u8p), img.shape[0], img.shape[1], img.strides[0],
+                                              float(clip_limit), int(tiles[0]), int(tiles[1]), _ptr(out, c_u8p)))
+        return out
+
+    def resize_area(self, img, dsize):
+        """cv2.resize(img, dsize=(width, height), interpolation=INTER_AREA)."""
+        img = self._gray(img)
+        dw, dh = int(dsize[0]), int(dsize[1])
+        out = np.empty((dh, dw), np.uint8)
+        with self.lock:
+            self._check(self.lib.imatch_resize_area(self._h, _ptr(img, c_u8p), img.shape[0], img.shape[1],
+                                                    img.strides[0], _ptr(out, c_u8p), dh, dw))
+        return out
+
+    def sift_extract(self, img, params=None):
+        """[CLAHE ->] SIFT detectAndCompute; the result is a Features set resident in HBM."""
+        img = self._gray(img)
+        params = params or SiftParams()
+        h = c_vp()
+        with self.lock:
+            self._check(self.lib.imatch_sift_extract(self._h, _ptr(img, c_u8p), img.shape[0], img.shape[1],
+                                                     img.strides[0], ctypes.byref(params), ctypes.byref(h)))
+            n = self.lib.imatch_features_count(h)
+        return Features(self, h, n)
+
+    def sift_debug_layer(self, kind, o, i):
+        r, c = ctypes.c_int(), ctypes.c_int()
+        with self.lock:
+            self._check(self.lib.imatch_sift_debug_layer(self._h, kind, o, i, None, ctypes.byref(r), ctypes.byref(c)))
+            out = np.empty((r.value, c.value), np.float32)
+            self._check(self.lib.imatch_sift_debug_layer(self._h, kind, o, i, _ptr(out, c_f32p), ctypes.byref(r),
+                                                         ctypes.byref(c)))
+        return out
+
+    def sift_debug_octaves(self):
+        return self.lib.imatch_sift_debug_octaves(self._h)
 
     # -- kNN ---------------------------------------------------------------------------
     def knn2(self, q, t):

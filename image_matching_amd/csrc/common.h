@@ -16,6 +16,11 @@ struct imatch_ctx {
     // pinned host staging
     void* hs;
     size_t hs_bytes;
+    // optional event bracket around the dominant kernel (imatch_set_profiling)
+    int prof;
+    hipEvent_t ev0, ev1;
+    // SIFT pyramid arena of the last extraction (kept for reuse by the next frame of the same size)
+    struct imatch_sift_state* sift;
 };
 
 struct imatch_features {
@@ -26,10 +31,17 @@ struct imatch_features {
     float* norm;      // f32 [n_pad] squared L2 norms (exact integers for integral sets), device
     int* flag;        // device int: 1 if some value was not an integer in 0..255
     int integral;     // host copy of !flag, valid after creation
+    // sets produced by imatch_sift_extract also carry:
+    float* kp;        // host [n][7] keypoint records (final order), or null
+    uint8_t* image;   // device [img_h][img_w] CLAHE output, or null
+    int img_h, img_w;
 };
 
 #define IMATCH_ROW_PAD 1024
 
+int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out);
+int imatch_features_pack_u8_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev);
+void imatch_sift_state_free(imatch_ctx* ctx);
 int imatch_set_err(imatch_ctx* ctx, int code, const char* fmt, ...);
 int imatch_ws_reserve(imatch_ctx* ctx, size_t bytes);
 int imatch_hs_reserve(imatch_ctx* ctx, size_t bytes);

@@ -69,8 +69,11 @@ void imatch_destroy(imatch_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    imatch_sift_state_free(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->hs) (void)hipHostFree(ctx->hs);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -78,6 +81,25 @@ void imatch_destroy(imatch_ctx* ctx) {
 const char* imatch_last_error(const imatch_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
 void* imatch_stream(imatch_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int imatch_set_profiling(imatch_ctx* ctx, int on) {
+    if (!ctx) return IMATCH_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (on && !ctx->ev0) {
+        HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
+        HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
+    }
+    ctx->prof = on ? 1 : 0;
+    return IMATCH_OK;
+}
+
+int imatch_knn2_kernel_ms(imatch_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return IMATCH_EINVAL;
+    if (!ctx->ev0) return imatch_set_err(ctx, IMATCH_EINVAL, "profiling was never enabled");
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return IMATCH_OK;
+}
 
 int imatch_synchronize(imatch_ctx* ctx) {
     if (!ctx) return IMATCH_EINVAL;

@@ -270,7 +270,7 @@ __global__ void pack_rows_kernel(const T* __restrict__ src, int64_t n, int64_t n
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(flag, 1);
 }
 
-static int features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out) {
+int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out) {
     imatch_features* f = (imatch_features*)calloc(1, sizeof(imatch_features));
     if (!f) return imatch_set_err(ctx, IMATCH_ENOMEM, "host alloc");
     f->ctx = ctx;
@@ -304,6 +304,10 @@ static int features_pack(imatch_ctx* ctx, imatch_features* f, const T* src_dev) 
     return IMATCH_OK;
 }
 
+int imatch_features_pack_u8_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev) {
+    return features_pack<uint8_t>(ctx, f, src_dev);
+}
+
 template <typename T>
 static int features_from_host(imatch_ctx* ctx, const T* desc, int64_t n, int d, imatch_features** out) {
     if (!ctx || !out || n < 0 || (n > 0 && !desc)) return imatch_set_err(ctx, IMATCH_EINVAL, "null or negative argument");
@@ -312,7 +316,7 @@ static int features_from_host(imatch_ctx* ctx, const T* desc, int64_t n, int d, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     *out = nullptr;
     imatch_features* f = nullptr;
-    int rc = features_alloc(ctx, n, &f);
+    int rc = imatch_features_alloc(ctx, n, &f);
     if (rc) return rc;
     const size_t bytes = (size_t)n * 128 * sizeof(T);
     rc = imatch_ws_reserve(ctx, bytes ? bytes : 16);
@@ -360,10 +364,12 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     if (rc) return rc;
     float2* pb = (float2*)ctx->ws;
     int2* pi = (int2*)((char*)ctx->ws + pbytes);
+    if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (QB == 4) launch_knn<4, 4>(ctx, q, t, nQt, nChunks, nStages, Qpad, pb, pi);
     else if (QB == 2) launch_knn<4, 2>(ctx, q, t, nQt, nChunks, nStages, Qpad, pb, pi);
     else launch_knn<4, 1>(ctx, q, t, nQt, nChunks, nStages, Qpad, pb, pi);
     HIP_TRY(ctx, hipGetLastError());
+    if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     // rows of query tiles beyond nQt are never written by the main kernel but are >= q->n: not read
     hipLaunchKernelGGL(knn2_finish_kernel, dim3((unsigned)((q->n + 255) / 256)), dim3(256), 0, ctx->stream, pb, pi,
                        (int)nLists, Qpad, q->norm, q->n, t->n, idx_offset, (int4*)out4_dev);
@@ -388,7 +394,7 @@ int imatch_features_from_device_u8(imatch_ctx* ctx, const uint8_t* desc_dev, int
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     *out = nullptr;
     imatch_features* f = nullptr;
-    int rc = features_alloc(ctx, n, &f);
+    int rc = imatch_features_alloc(ctx, n, &f);
     if (rc) return rc;
     rc = features_pack<uint8_t>(ctx, f, desc_dev);
     if (rc) { imatch_features_free(f); return rc; }
@@ -409,6 +415,8 @@ void imatch_features_free(imatch_features* f) {
     if (f->desc) (void)hipFree(f->desc);
     if (f->norm) (void)hipFree(f->norm);
     if (f->flag) (void)hipFree(f->flag);
+    if (f->image) (void)hipFree(f->image);
+    free(f->kp);
     free(f);
 }
 

@@ -1,0 +1,260 @@
+// Pre-processing kernels: CLAHE and INTER_AREA resize for 8-bit gray images.
+// Replace cv2.createCLAHE(...).apply (reference match_finder.py:200-203) and
+// cv2.resize(..., INTER_AREA) (reference utils.py:17-22). Both are byte-streaming, HBM-bound
+// kernels; arithmetic follows OpenCV's order (unfused f32 products and sums), so results are
+// bit-identical to the oracle.
+#include "common.h"
+#include "preproc.h"
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+__device__ __forceinline__ uint8_t sat_u8(float v) {
+    int i = __float2int_rn(v);  // round half to even, as cvRound
+    return (uint8_t)min(max(i, 0), 255);
+}
+
+// ---- CLAHE ---------------------------------------------------------------------------------
+// grid (tiles_x*tiles_y, slices): each block histograms a band of rows of one tile
+__global__ void __launch_bounds__(256)
+clahe_hist_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, int tw, int th, int tiles_x,
+                  int* __restrict__ hist) {
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile % tiles_x;
+    const int band = (th + gridDim.y - 1) / gridDim.y;
+    const int y0 = blockIdx.y * band, y1 = min(th, y0 + band);
+    for (int y = y0 + (threadIdx.x >> 6); y < y1; y += 4) {
+        const uint8_t* p = src + (size_t)reflect101(ty * th + y, rows) * stride;
+        for (int x = threadIdx.x & 63; x < tw; x += 64) atomicAdd(&h[p[reflect101(tx * tw + x, cols)]], 1);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[tile * 256 + threadIdx.x], h[threadIdx.x]);
+}
+
+// one block per tile: clip, redistribute, cumulative sum -> LUT
+__global__ void __launch_bounds__(256)
+clahe_lut_kernel(const int* __restrict__ hist, int clip, float lut_scale, uint8_t* __restrict__ lut) {
+    __shared__ int s[256];
+    __shared__ int total;
+    const int i = threadIdx.x;
+    int v = hist[blockIdx.x * 256 + i];
+    if (clip > 0) {
+        const int over = v > clip ? v - clip : 0;
+        if (v > clip) v = clip;
+        if (i == 0) total = 0;
+        __syncthreads();
+        if (over) atomicAdd(&total, over);
+        __syncthreads();
+        const int clipped = total;
+        const int batch = clipped / 256;
+        const int residual = clipped - batch * 256;
+        v += batch;
+        if (residual != 0) {
+            const int step = max(256 / residual, 1);
+            // for (k = 0; k < 256 && residual > 0; k += step, residual--) hist[k]++
+            if (i % step == 0 && i / step < residual) v += 1;
+        }
+    }
+    s[i] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int t = i >= o ? s[i - o] : 0;
+        __syncthreads();
+        s[i] += t;
+        __syncthreads();
+    }
+    lut[blockIdx.x * 256 + i] = sat_u8((float)s[i] * lut_scale);
+}
+
+__global__ void __launch_bounds__(256)
+clahe_apply_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, int tw, int th, int tiles_x,
+                   int tiles_y, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    const float tyf = y * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = max(ty1, 0);
+    ty2 = min(ty2, tiles_y - 1);
+    const float txf = x * inv_tw - 0.5f;
+    int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+    const float xa = txf - tx1, xa1 = 1.0f - xa;
+    tx1 = max(tx1, 0);
+    tx2 = min(tx2, tiles_x - 1);
+    const int v = src[(size_t)y * stride + x];
+    const float l11 = lut[(ty1 * tiles_x + tx1) * 256 + v], l12 = lut[(ty1 * tiles_x + tx2) * 256 + v];
+    const float l21 = lut[(ty2 * tiles_x + tx1) * 256 + v], l22 = lut[(ty2 * tiles_x + tx2) * 256 + v];
+    const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+    dst[(size_t)y * cols + x] = sat_u8(res);
+}
+
+int imatch_clahe_dev(imatch_ctx* ctx, const uint8_t* src_dev, int h, int w, int stride, double clip_limit, int tiles_x,
+                     int tiles_y, uint8_t* dst_dev, void* scratch /* >= tiles*(1024+256) bytes */) {
+    int eh = h, ew = w;
+    if (w % tiles_x != 0 || h % tiles_y != 0) {
+        eh = h + (tiles_y - h % tiles_y);
+        ew = w + (tiles_x - w % tiles_x);
+    }
+    const int tw = ew / tiles_x, th = eh / tiles_y, tiles = tiles_x * tiles_y;
+    const int total = tw * th;
+    int clip = 0;
+    if (clip_limit > 0.0) {
+        clip = (int)(clip_limit * total / 256);
+        if (clip < 1) clip = 1;
+    }
+    int* hist = (int*)scratch;
+    uint8_t* lut = (uint8_t*)scratch + (size_t)tiles * 1024;
+    HIP_TRY(ctx, hipMemsetAsync(hist, 0, (size_t)tiles * 1024, ctx->stream));
+    int slices = (th + 63) / 64;
+    if (slices > 64) slices = 64;
+    hipLaunchKernelGGL(clahe_hist_kernel, dim3(tiles, slices), dim3(256), 0, ctx->stream, src_dev, h, w, stride, tw, th,
+                       tiles_x, hist);
+    hipLaunchKernelGGL(clahe_lut_kernel, dim3(tiles), dim3(256), 0, ctx->stream, hist, clip, (float)255 / total, lut);
+    hipLaunchKernelGGL(clahe_apply_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, ctx->stream, src_dev, h, w,
+                       stride, tw, th, tiles_x, tiles_y, lut, dst_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return IMATCH_OK;
+}
+
+// ---- INTER_AREA ----------------------------------------------------------------------------
+// One thread per output pixel. The decimation table of resize.cpp:computeResizeAreaTab is
+// recomputed per thread in double (3 kinds of entry: a fractional head, whole cells, a fractional
+// tail); the row sums and the beta-weighted column sum follow ResizeArea_Invoker's order.
+struct area_span {
+    int s_head, s1, s2, s_tail;  // head source index or -1; whole cells [s1, s2); tail index or -1
+    float a_head, a_mid, a_tail;
+};
+
+__device__ __forceinline__ area_span area_entry(int d, double scale, int ssize) {
+    area_span e;
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, ssize - f1);
+    int sx1 = (int)ceil(f1), sx2 = (int)floor(f2);
+    sx2 = min(sx2, ssize - 1);
+    sx1 = min(sx1, sx2);
+    e.s_head = -1;
+    e.s_tail = -1;
+    e.a_head = e.a_tail = 0.f;
+    if (sx1 - f1 > 1e-3) {
+        e.s_head = sx1 - 1;
+        e.a_head = (float)((sx1 - f1) / cell);
+    }
+    e.s1 = sx1;
+    e.s2 = sx2;
+    e.a_mid = (float)(1.0 / cell);
+    if (f2 - sx2 > 1e-3) {
+        e.s_tail = sx2;
+        e.a_tail = (float)(fmin(fmin(f2 - sx2, 1.), cell) / cell);
+    }
+    return e;
+}
+
+__device__ __forceinline__ float area_row(const uint8_t* __restrict__ S, const area_span& ex) {
+    float buf = 0.f;
+    if (ex.s_head >= 0) buf += S[ex.s_head] * ex.a_head;
+    for (int sx = ex.s1; sx < ex.s2; ++sx) buf += S[sx] * ex.a_mid;
+    if (ex.s_tail >= 0) buf += S[ex.s_tail] * ex.a_tail;
+    return buf;
+}
+
+__global__ void __launch_bounds__(256)
+resize_area_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, uint8_t* __restrict__ dst, int drows,
+                   int dcols, double scale_x, double scale_y) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dcols || dy >= drows) return;
+    const area_span ex = area_entry(dx, scale_x, cols), ey = area_entry(dy, scale_y, rows);
+    float sum = 0.f;
+    if (ey.s_head >= 0) sum += ey.a_head * area_row(src + (size_t)ey.s_head * stride, ex);
+    for (int sy = ey.s1; sy < ey.s2; ++sy) sum += ey.a_mid * area_row(src + (size_t)sy * stride, ex);
+    if (ey.s_tail >= 0) sum += ey.a_tail * area_row(src + (size_t)ey.s_tail * stride, ex);
+    dst[(size_t)dy * dcols + dx] = sat_u8(sum);
+}
+
+// integer factors: ResizeAreaFast (2x2: (a+b+c+d+2)>>2, otherwise sum * (1/area))
+__global__ void __launch_bounds__(256)
+resize_area_fast_kernel(const uint8_t* __restrict__ src, int stride, uint8_t* __restrict__ dst, int drows, int dcols,
+                        int isx, int isy) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dcols || dy >= drows) return;
+    int sum = 0;
+    for (int j = 0; j < isy; ++j)
+        for (int i = 0; i < isx; ++i) sum += src[(size_t)(dy * isy + j) * stride + dx * isx + i];
+    const float scale = 1.f / (isx * isy);
+    dst[(size_t)dy * dcols + dx] = (isx == 2 && isy == 2) ? (uint8_t)((sum + 2) >> 2) : sat_u8((float)sum * scale);
+}
+
+int imatch_resize_area_dev(imatch_ctx* ctx, const uint8_t* src_dev, int h, int w, int stride, uint8_t* dst_dev, int dh,
+                           int dw) {
+    const double inv_x = (double)dw / w, inv_y = (double)dh / h;
+    const double sx = 1. / inv_x, sy = 1. / inv_y;
+    const int isx = (int)lrint(sx), isy = (int)lrint(sy);
+    const dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    if (fabs(sx - isx) < 2.220446049250313e-16 && fabs(sy - isy) < 2.220446049250313e-16)
+        hipLaunchKernelGGL(resize_area_fast_kernel, grid, dim3(256), 0, ctx->stream, src_dev, stride, dst_dev, dh, dw, isx,
+                           isy);
+    else
+        hipLaunchKernelGGL(resize_area_kernel, grid, dim3(256), 0, ctx->stream, src_dev, h, w, stride, dst_dev, dh, dw, sx,
+                           sy);
+    HIP_TRY(ctx, hipGetLastError());
+    return IMATCH_OK;
+}
+
+// ---- host-pointer entry points ---------------------------------------------------------------
+static int upload_image(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, uint8_t* dev) {
+    HIP_TRY(ctx, hipMemcpy2DAsync(dev, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice,
+                                  ctx->stream));
+    return IMATCH_OK;
+}
+
+extern "C" {
+
+int imatch_clahe(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, double clip_limit, int tiles_x,
+                 int tiles_y, uint8_t* out) {
+    if (!ctx || !img || !out || h <= 0 || w <= 0 || stride < w || tiles_x <= 0 || tiles_y <= 0 || tiles_x * tiles_y > 4096)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t px = ((size_t)h * w + 255) & ~(size_t)255;
+    const size_t scratch = (size_t)tiles_x * tiles_y * 1280;
+    int rc = imatch_ws_reserve(ctx, 2 * px + scratch);
+    if (rc) return rc;
+    uint8_t* src = (uint8_t*)ctx->ws;
+    uint8_t* dst = src + px;
+    rc = upload_image(ctx, img, h, w, stride, src);
+    if (rc) return rc;
+    rc = imatch_clahe_dev(ctx, src, h, w, w, clip_limit, tiles_x, tiles_y, dst, dst + px);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, dst, (size_t)h * w, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return IMATCH_OK;
+}
+
+int imatch_resize_area(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, uint8_t* out, int dh, int dw) {
+    if (!ctx || !img || !out || h <= 0 || w <= 0 || stride < w || dh <= 0 || dw <= 0)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    if (dh > h || dw > w)
+        return imatch_set_err(ctx, IMATCH_ESIZE, "INTER_AREA enlargement (%dx%d -> %dx%d) is not implemented", w, h, dw, dh);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t px = ((size_t)h * w + 255) & ~(size_t)255;
+    int rc = imatch_ws_reserve(ctx, px + (size_t)dh * dw);
+    if (rc) return rc;
+    uint8_t* src = (uint8_t*)ctx->ws;
+    uint8_t* dst = src + px;
+    rc = upload_image(ctx, img, h, w, stride, src);
+    if (rc) return rc;
+    rc = imatch_resize_area_dev(ctx, src, h, w, w, dst, dh, dw);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, dst, (size_t)dh * dw, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return IMATCH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,824 @@
+// SIFT detectAndCompute on gfx950: replaces the body of match_finder.find_kp_dp
+// (reference match_finder.py:199-221 with the SIFT call of match_finder.py:205-209).
+//
+// Stages (all f32, the arithmetic order follows OpenCV's sift.simd.hpp so that the pyramid is
+// bit-identical to the CPU oracle; -ffp-contract=off, every fma below is explicit):
+//   upsample2   u8 -> f32, x2 bilinear (createInitialImage)
+//   blur<R>     separable Gaussian, one 64x64 tile per workgroup staged through LDS with its
+//               halo; row pass and column pass use register sliding windows; the DoG layer
+//               (output - input) is written by the same kernel, so each pyramid layer is read
+//               once and written once
+//   decimate    next octave's layer 0 = every second pixel of layer nOctaveLayers
+//   detect      26-neighbour extremum scan over the DoG triplets -> candidate list (atomic append)
+//   refine      adjustLocalExtrema: <=5 Newton steps (3x3 Cramer solve), contrast and edge tests
+//   orient      one wavefront per keypoint: 36-bin gradient histogram, smoothing, peaks
+//   (host)      KeyPointsFilter::removeDuplicatedSorted order + first-octave rescale
+//   describe    one wavefront per keypoint: 4x4x8 trilinear histogram, normalise, clamp, x512, u8
+// Histograms accumulate in 64-bit fixed point (2^-20) through LDS atomics: integer adds commute,
+// so results do not depend on the order in which lanes arrive.
+#include "common.h"
+#include "preproc.h"
+#include <algorithm>
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
+
+#define MAX_OCT 16
+#define MAX_LAY 8
+#define SIFT_IMG_BORDER 5
+#define SIFT_MAX_INTERP_STEPS 5
+#define SIFT_ORI_HIST_BINS 36
+#define FIX_SCALE 1048576.0f
+#define FIX_INV (1.0f / 1048576.0f)
+
+struct PyrTable {
+    float* gauss[MAX_OCT][MAX_LAY];
+    float* dog[MAX_OCT][MAX_LAY];
+    int rows[MAX_OCT], cols[MAX_OCT];
+    int n_oct, nl;
+};
+
+struct RefinedKp {   // output of refine, input of orient
+    float x, y, size, response;
+    int octave;      // packed: o + (layer << 8) + (cvRound((xi+0.5)*255) << 16)
+    int o, layer, r, c;
+};
+
+struct KpRec {       // cv2.KeyPoint fields
+    float x, y, size, angle, response;
+    int octave;
+};
+
+struct imatch_sift_state {
+    char* arena;
+    size_t arena_bytes;
+    PyrTable T;
+    int h, w;
+};
+
+void imatch_sift_state_free(imatch_ctx* ctx) {
+    if (!ctx || !ctx->sift) return;
+    if (ctx->sift->arena) (void)hipFree(ctx->sift->arena);
+    free(ctx->sift);
+    ctx->sift = nullptr;
+}
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+// ---- createInitialImage: u8 -> f32, x2 INTER_LINEAR ------------------------------------------
+__global__ void __launch_bounds__(256)
+upsample2_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, float* __restrict__ dst) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= 2 * cols || dy >= 2 * rows) return;
+    float fx = (float)((dx + 0.5) * 0.5 - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= cols - 1) { fx = 0; sx = cols - 1; }
+    float fy = (float)((dy + 0.5) * 0.5 - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    if (sy < 0) { fy = 0; sy = 0; }
+    if (sy >= rows - 1) { fy = 0; sy = rows - 1; }
+    const int sx1 = min(sx + 1, cols - 1), sy1 = min(sy + 1, rows - 1);
+    const uint8_t* s0 = src + (size_t)sy * stride;
+    const uint8_t* s1 = src + (size_t)sy1 * stride;
+    const float a1 = fx, a0 = 1.f - a1;
+    const float h0 = s0[sx] * a0 + s0[sx1] * a1;
+    const float h1 = s1[sx] * a0 + s1[sx1] * a1;
+    dst[(size_t)dy * (2 * cols) + dx] = h0 * (1.f - fy) + h1 * fy;
+}
+
+// ---- GaussianBlur (+ DoG) ---------------------------------------------------------------------
+template <int R>
+struct GK { float k[2 * R + 1]; };
+
+template <int R>
+__global__ void __launch_bounds__(256)
+blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int rows, int cols, GK<R> gk) {
+    constexpr int N = 2 * R + 1, W2 = 64 + 2 * R, H2 = 64 + 2 * R, PITCH = (W2 + 3) & ~3;
+    __shared__ float in[H2 * PITCH];
+    __shared__ float tmp[H2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    for (int y = wave; y < H2; y += 4) {
+        const float* s = src + (size_t)reflect101(y0 - R + y, rows) * cols;
+        for (int x = lane; x < W2; x += 64) in[y * PITCH + x] = s[reflect101(x0 - R + x, cols)];
+    }
+    __syncthreads();
+    // row pass: 16 threads per row, 4 consecutive outputs each, taps in ascending order
+    {
+        const int xq = (tid & 15) * 4;
+        for (int y = tid >> 4; y < H2; y += 16) {
+            float v[N + 3];
+#pragma unroll
+            for (int i = 0; i < N + 3; ++i) v[i] = in[y * PITCH + xq + i];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int t = 0; t < N; ++t) {
+                const float k = gk.k[t];
+                a0 = fmaf(k, v[t], a0);
+                a1 = fmaf(k, v[t + 1], a1);
+                a2 = fmaf(k, v[t + 2], a2);
+                a3 = fmaf(k, v[t + 3], a3);
+            }
+            *(float4*)&tmp[y * 64 + xq] = make_float4(a0, a1, a2, a3);
+        }
+    }
+    __syncthreads();
+    // column pass: lane = column, each wave 16 output rows
+    {
+        float v[16 + 2 * R];
+#pragma unroll
+        for (int i = 0; i < 16 + 2 * R; ++i) v[i] = tmp[(16 * wave + i) * 64 + lane];
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const float k = gk.k[t];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(k, v[t + j], acc[j]);
+        }
+        const int gx = x0 + lane;
+        if (gx < cols) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int gy = y0 + 16 * wave + j;
+                if (gy < rows) {
+                    dst[(size_t)gy * cols + gx] = acc[j];
+                    if (dog) dog[(size_t)gy * cols + gx] = acc[j] - in[(16 * wave + j + R) * PITCH + lane + R];
+                }
+            }
+        }
+    }
+}
+
+// any other radius (non-default sigma / nOctaveLayers): plain per-tap loops, same arithmetic order
+#define RT_MAXR 20
+struct GKrt { int r; float k[2 * RT_MAXR + 1]; };
+
+__global__ void __launch_bounds__(256)
+blur_rows_rt_kernel(const float* __restrict__ src, float* __restrict__ tmp, int rows, int cols, GKrt gk) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const float* s = src + (size_t)y * cols;
+    float acc = 0.f;
+    for (int t = 0; t < 2 * gk.r + 1; ++t) acc = fmaf(gk.k[t], s[reflect101(x + t - gk.r, cols)], acc);
+    tmp[(size_t)y * cols + x] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+blur_cols_rt_kernel(const float* __restrict__ tmp, const float* __restrict__ src, float* __restrict__ dst,
+                    float* __restrict__ dog, int rows, int cols, GKrt gk) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    float acc = 0.f;
+    for (int t = 0; t < 2 * gk.r + 1; ++t) acc = fmaf(gk.k[t], tmp[(size_t)reflect101(y + t - gk.r, rows) * cols + x], acc);
+    dst[(size_t)y * cols + x] = acc;
+    if (dog) dog[(size_t)y * cols + x] = acc - src[(size_t)y * cols + x];
+}
+
+__global__ void __launch_bounds__(256)
+decimate_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst, int rows, int cols) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    dst[(size_t)y * cols + x] = src[(size_t)(2 * y) * scols + 2 * x];
+}
+
+// ---- findScaleSpaceExtrema: candidate scan ------------------------------------------------------
+__global__ void __launch_bounds__(256)
+detect_kernel(PyrTable T, int o, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count) {
+    const int cols = T.cols[o], rows = T.rows[o];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63) + SIFT_IMG_BORDER;
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6) + SIFT_IMG_BORDER;
+    if (c >= cols - SIFT_IMG_BORDER || r >= rows - SIFT_IMG_BORDER) return;
+    for (int i = 1; i <= T.nl; ++i) {
+        const float* img = T.dog[o][i];
+        const float val = img[(size_t)r * cols + c];
+        if (!(fabsf(val) > thr)) continue;
+        const float* prev = T.dog[o][i - 1];
+        const float* next = T.dog[o][i + 1];
+        bool is_max = val > 0, is_min = val < 0;
+        for (int dr = -1; dr <= 1 && (is_max || is_min); ++dr) {
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                const size_t p = (size_t)(r + dr) * cols + c + dc;
+                const float a = img[p], b = prev[p], d = next[p];
+                is_max = is_max && val >= a && val >= b && val >= d;
+                is_min = is_min && val <= a && val <= b && val <= d;
+            }
+        }
+        if (is_max || is_min) {
+            const int k = atomicAdd(count, 1);
+            if (k < cap) cand[k] = make_uint2((unsigned)((o << 8) | i), (unsigned)((r << 16) | c));
+        }
+    }
+}
+
+// ---- adjustLocalExtrema ---------------------------------------------------------------------------
+__device__ __forceinline__ void solve3(const float a[3][3], const float b[3], float x[3]) {
+    float d = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+              a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    if (d == 0) { x[0] = x[1] = x[2] = 0; return; }
+    d = 1 / d;
+    x[0] = d * (b[0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (b[1] * a[2][2] - a[1][2] * b[2]) +
+                a[0][2] * (b[1] * a[2][1] - a[1][1] * b[2]));
+    x[1] = d * (a[0][0] * (b[1] * a[2][2] - a[1][2] * b[2]) - b[0] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                a[0][2] * (a[1][0] * b[2] - b[1] * a[2][0]));
+    x[2] = d * (a[0][0] * (a[1][1] * b[2] - b[1] * a[2][1]) - a[0][1] * (a[1][0] * b[2] - b[1] * a[2][0]) +
+                b[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]));
+}
+
+__global__ void __launch_bounds__(256)
+refine_kernel(PyrTable T, const uint2* __restrict__ cand, int n_cand, float contrast_thr, float edge_thr, float sigma,
+              RefinedKp* __restrict__ out, int* __restrict__ count) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= n_cand) return;
+    const uint2 cd = cand[id];
+    const int octv = cd.x >> 8;
+    int layer = cd.x & 255, r = cd.y >> 16, c = cd.y & 0xffff;
+    const int nl = T.nl, rows = T.rows[octv], cols = T.cols[octv];
+    const float img_scale = 1.f / 255, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale,
+                cross_deriv_scale = img_scale * 0.25f;
+    float xi = 0, xr = 0, xc = 0;
+    int i = 0;
+#define AT(p, rr, cc) (p)[(size_t)(rr) * cols + (cc)]
+    for (; i < SIFT_MAX_INTERP_STEPS; i++) {
+        const float* img = T.dog[octv][layer];
+        const float* prev = T.dog[octv][layer - 1];
+        const float* next = T.dog[octv][layer + 1];
+        const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
+                             (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
+                             (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
+        const float v2 = AT(img, r, c) * 2;
+        const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_deriv_scale;
+        const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_deriv_scale;
+        const float dss = (AT(next, r, c) + AT(prev, r, c) - v2) * second_deriv_scale;
+        const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_deriv_scale;
+        const float dxs = (AT(next, r, c + 1) - AT(next, r, c - 1) - AT(prev, r, c + 1) + AT(prev, r, c - 1)) * cross_deriv_scale;
+        const float dys = (AT(next, r + 1, c) - AT(next, r - 1, c) - AT(prev, r + 1, c) + AT(prev, r - 1, c)) * cross_deriv_scale;
+        const float H[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+        float X[3];
+        solve3(H, dD, X);
+        xi = -X[2]; xr = -X[1]; xc = -X[0];
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        if (fabsf(xi) > (float)(INT_MAX / 3) || fabsf(xr) > (float)(INT_MAX / 3) || fabsf(xc) > (float)(INT_MAX / 3)) return;
+        c += __float2int_rn(xc); r += __float2int_rn(xr); layer += __float2int_rn(xi);
+        if (layer < 1 || layer > nl || c < SIFT_IMG_BORDER || c >= cols - SIFT_IMG_BORDER || r < SIFT_IMG_BORDER ||
+            r >= rows - SIFT_IMG_BORDER)
+            return;
+    }
+    if (i >= SIFT_MAX_INTERP_STEPS) return;
+    float contr;
+    {
+        const float* img = T.dog[octv][layer];
+        const float* prev = T.dog[octv][layer - 1];
+        const float* next = T.dog[octv][layer + 1];
+        const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
+                             (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
+                             (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
+        const float t = dD[0] * xc + dD[1] * xr + dD[2] * xi;
+        contr = AT(img, r, c) * img_scale + t * 0.5f;
+        if (fabsf(contr) * nl < contrast_thr) return;
+        const float v2 = AT(img, r, c) * 2.f;
+        const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_deriv_scale;
+        const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_deriv_scale;
+        const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_deriv_scale;
+        const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+        if (det <= 0 || tr * tr * edge_thr >= (edge_thr + 1) * (edge_thr + 1) * det) return;
+    }
+#undef AT
+    RefinedKp k;
+    k.x = (c + xc) * (1 << octv);
+    k.y = (r + xr) * (1 << octv);
+    k.octave = octv + (layer << 8) + ((int)rint(((double)xi + 0.5) * 255) << 16);
+    k.size = sigma * powf(2.f, (layer + xi) / nl) * (1 << octv) * 2;
+    k.response = fabsf(contr);
+    k.o = octv; k.layer = layer; k.r = r; k.c = c;
+    out[atomicAdd(count, 1)] = k;
+}
+
+__device__ __forceinline__ float atan2_deg(float y, float x) {
+    float a = atan2f(y, x) * (float)(180.0 / M_PI);
+    if (a < 0) a += 360.f;
+    return a;
+}
+
+// ---- calcOrientationHist + peak picking: one wavefront per refined keypoint ---------------------
+__global__ void __launch_bounds__(256)
+orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, int n_ref, KpRec* __restrict__ out, int cap,
+              int* __restrict__ count) {
+    __shared__ unsigned long long hacc[4][SIFT_ORI_HIST_BINS];
+    __shared__ float hsm[4][SIFT_ORI_HIST_BINS + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int id = blockIdx.x * 4 + wave;
+    const bool active = id < n_ref;
+    const int n = SIFT_ORI_HIST_BINS;
+    if (lane < n) hacc[wave][lane] = 0ull;
+    __syncthreads();
+    RefinedKp k;
+    if (active) {
+        k = ref[id];
+        const int rows = T.rows[k.o], cols = T.cols[k.o];
+        const float* img = T.gauss[k.o][k.layer];
+        const float scl_octv = k.size * 0.5f / (1 << k.o);
+        const int radius = __float2int_rn(4.5f * scl_octv);
+        const float sigma = 1.5f * scl_octv;
+        const float expf_scale = -1.f / (2.f * sigma * sigma);
+        const int side = 2 * radius + 1;
+        for (int p = lane; p < side * side; p += 64) {
+            const int i = p / side - radius, j = p % side - radius;
+            const int y = k.r + i, x = k.c + j;
+            if (y <= 0 || y >= rows - 1 || x <= 0 || x >= cols - 1) continue;
+            const float dx = img[(size_t)y * cols + x + 1] - img[(size_t)y * cols + x - 1];
+            const float dy = img[(size_t)(y - 1) * cols + x] - img[(size_t)(y + 1) * cols + x];
+            const float w = expf((i * i + j * j) * expf_scale);
+            const float ori = atan2_deg(dy, dx);
+            const float mag = sqrtf(dx * dx + dy * dy);
+            int bin = __float2int_rn((n / 360.f) * ori);
+            if (bin >= n) bin -= n;
+            if (bin < 0) bin += n;
+            atomicAdd(&hacc[wave][bin], (unsigned long long)(long long)__float2int_rn(w * mag * FIX_SCALE));
+        }
+    }
+    __syncthreads();
+    if (lane < n) hsm[wave][lane + 2] = (float)(long long)hacc[wave][lane] * FIX_INV;
+    __syncthreads();
+    if (lane == 0) {
+        float* th = &hsm[wave][2];
+        th[-1] = th[n - 1]; th[-2] = th[n - 2]; th[n] = th[0]; th[n + 1] = th[1];
+    }
+    __syncthreads();
+    float hv = 0.f;
+    if (lane < n) {
+        const float* th = &hsm[wave][2];
+        hv = (th[lane - 2] + th[lane + 2]) * (1.f / 16.f) + (th[lane - 1] + th[lane + 1]) * (4.f / 16.f) +
+             th[lane] * (6.f / 16.f);
+    }
+    float mx = lane < n ? hv : -FLT_MAX;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    __syncthreads();
+    if (lane < n) hsm[wave][lane] = hv;  // smoothed histogram, plain indexing from here
+    __syncthreads();
+    if (!active || lane >= n) return;
+    const float mag_thr = (float)(mx * 0.8f);
+    const int j = lane, l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
+    const float hl = hsm[wave][l], hj = hsm[wave][j], hr = hsm[wave][r2];
+    if (hj > hl && hj > hr && hj >= mag_thr) {
+        float bin = j + 0.5f * (hl - hr) / (hl - 2 * hj + hr);
+        bin = bin < 0 ? n + bin : bin >= n ? bin - n : bin;
+        float angle = 360.f - (float)((360.f / n) * bin);
+        if (fabsf(angle - 360.f) < FLT_EPSILON) angle = 0.f;
+        const int slot = atomicAdd(count, 1);
+        if (slot < cap) {
+            KpRec o;
+            o.x = k.x; o.y = k.y; o.size = k.size; o.angle = angle; o.response = k.response; o.octave = k.octave;
+            out[slot] = o;
+        }
+    }
+}
+
+// ---- calcSIFTDescriptor: one wavefront per (sorted) keypoint -------------------------------------
+#define DESC_HIST (6 * 6 * 10)
+__global__ void __launch_bounds__(256)
+describe_kernel(PyrTable T, const KpRec* __restrict__ kps, int n_kp, int first_octave, uint8_t* __restrict__ desc) {
+    __shared__ unsigned long long hist[4][DESC_HIST];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int id = blockIdx.x * 4 + wave;
+    for (int i = lane; i < DESC_HIST; i += 64) hist[wave][i] = 0ull;
+    __syncthreads();
+    const bool active = id < n_kp;
+    const int d = 4, n = 8;
+    if (active) {
+        const KpRec kp = kps[id];
+        int octave = kp.octave & 255;
+        const int layer = (kp.octave >> 8) & 255;
+        octave = octave < 128 ? octave : (-128 | octave);
+        const float scale = octave >= 0 ? 1.f / (1 << octave) : (float)(1 << -octave);
+        const float size = kp.size * scale;
+        const float ptx = kp.x * scale, pty = kp.y * scale;
+        const int o = octave - first_octave;
+        const float* img = T.gauss[o][layer];
+        const int rows = T.rows[o], cols = T.cols[o];
+        float ori = 360.f - kp.angle;
+        if (fabsf(ori - 360.f) < FLT_EPSILON) ori = 0.f;
+        const float scl = size * 0.5f;
+        const int px = __float2int_rn(ptx), py = __float2int_rn(pty);
+        float cos_t = cosf(ori * (float)(M_PI / 180));
+        float sin_t = sinf(ori * (float)(M_PI / 180));
+        const float bins_per_rad = n / 360.f;
+        const float exp_scale = -1.f / (d * d * 0.5f);
+        const float hist_width = 3.f * scl;
+        int radius = __float2int_rn(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
+        radius = min(radius, (int)sqrt(((double)cols) * cols + ((double)rows) * rows));
+        cos_t /= hist_width;
+        sin_t /= hist_width;
+        const int side = 2 * radius + 1;
+        for (int p = lane; p < side * side; p += 64) {
+            const int i = p / side - radius, j = p % side - radius;
+            const float c_rot = j * cos_t - i * sin_t;
+            const float r_rot = j * sin_t + i * cos_t;
+            float rbin = r_rot + d / 2 - 0.5f;
+            float cbin = c_rot + d / 2 - 0.5f;
+            const int r = py + i, c = px + j;
+            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1) {
+                const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1];
+                const float dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
+                const float w = expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+                float obin = (atan2_deg(dy, dx) - ori) * bins_per_rad;
+                const float mag = sqrtf(dx * dx + dy * dy) * w;
+                const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+                int o0 = (int)floorf(obin);
+                rbin -= r0; cbin -= c0; obin -= o0;
+                if (o0 < 0) o0 += n;
+                if (o0 >= n) o0 -= n;
+                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+                const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+                const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+                const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+                const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+                const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+                unsigned long long* hp = hist[wave];
+#define HADD(off, val) atomicAdd(&hp[idx + (off)], (unsigned long long)(long long)__float2int_rn((val) * FIX_SCALE))
+                HADD(0, v_rco000); HADD(1, v_rco001);
+                HADD(n + 2, v_rco010); HADD(n + 3, v_rco011);
+                HADD((d + 2) * (n + 2), v_rco100); HADD((d + 2) * (n + 2) + 1, v_rco101);
+                HADD((d + 3) * (n + 2), v_rco110); HADD((d + 3) * (n + 2) + 1, v_rco111);
+#undef HADD
+            }
+        }
+    }
+    __syncthreads();
+    // fold the circular orientation bins, normalise, clamp, renormalise, quantise
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int el = lane + 64 * e;
+        const int i = el >> 5, j = (el >> 3) & 3, k = el & 7;
+        const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+        long long s = (long long)hist[wave][idx + k];
+        if (k < 2) s += (long long)hist[wave][idx + n + k];
+        v[e] = (float)s * FIX_INV;
+    }
+    float nrm2 = v[0] * v[0] + v[1] * v[1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nrm2 += __shfl_xor(nrm2, o);
+    const float thr = sqrtf(nrm2) * 0.2f;
+    v[0] = fminf(v[0], thr);
+    v[1] = fminf(v[1], thr);
+    nrm2 = v[0] * v[0] + v[1] * v[1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nrm2 += __shfl_xor(nrm2, o);
+    nrm2 = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int q = __float2int_rn(v[e] * nrm2);
+            desc[(size_t)id * 128 + lane + 64 * e] = (uint8_t)min(max(q, 0), 255);
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+// getGaussianKernel(ksize, sigma, CV_32F), bit-exact form (see oracle/sift_oracle.c oracle_gauss_kernel)
+static int gauss_kernel(double sigma, float* k, int maxn) {
+    int n = (int)lrint(sigma * 4 * 2 + 1) | 1;
+    if (n > maxn) return -1;
+    const int n2 = (n - 1) / 2;
+    const double scale2x = -0.125 / (sigma * sigma);
+    std::vector<double> vals(n2 + 1);
+    double sum = 0;
+    for (int i = 0, x = 1 - n; i < n2; i++, x += 2) {
+        vals[i] = exp((double)(x * x) * scale2x);
+        sum += vals[i];
+    }
+    sum *= 2;
+    sum += 1.0;
+    const double mul1 = 1.0 / sum;
+    for (int i = 0; i < n2; i++) {
+        const double t = vals[i] * mul1;
+        k[i] = (float)t;
+        k[n - 1 - i] = (float)t;
+    }
+    k[n2] = (float)(1.0 * mul1);
+    return n;
+}
+
+template <int R>
+static void launch_blur_fixed(imatch_ctx* ctx, const float* src, float* dst, float* dog, int rows, int cols, const float* k) {
+    GK<R> gk;
+    memcpy(gk.k, k, sizeof(gk.k));
+    hipLaunchKernelGGL(blur_kernel<R>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, ctx->stream, src, dst, dog,
+                       rows, cols, gk);
+}
+
+// GaussianBlur(src, dst, Size(), sigma) [+ dog = dst - src]; tmp: scratch of the same size (runtime-radius path)
+static int gaussian_blur(imatch_ctx* ctx, const float* src, float* dst, float* dog, float* tmp, int rows, int cols,
+                         double sigma) {
+    float k[2 * RT_MAXR + 1];
+    const int n = gauss_kernel(sigma, k, 2 * RT_MAXR + 1);
+    if (n < 0) return imatch_set_err(ctx, IMATCH_ESIZE, "Gaussian sigma %g needs a kernel wider than %d", sigma, 2 * RT_MAXR + 1);
+    const int r = n / 2;
+    switch (r) {
+        case 4: launch_blur_fixed<4>(ctx, src, dst, dog, rows, cols, k); break;
+        case 5: launch_blur_fixed<5>(ctx, src, dst, dog, rows, cols, k); break;
+        case 6: launch_blur_fixed<6>(ctx, src, dst, dog, rows, cols, k); break;
+        case 8: launch_blur_fixed<8>(ctx, src, dst, dog, rows, cols, k); break;
+        case 10: launch_blur_fixed<10>(ctx, src, dst, dog, rows, cols, k); break;
+        case 13: launch_blur_fixed<13>(ctx, src, dst, dog, rows, cols, k); break;
+        default: {
+            GKrt gk;
+            gk.r = r;
+            memcpy(gk.k, k, sizeof(float) * n);
+            const dim3 grid((cols + 63) / 64, (rows + 3) / 4);
+            hipLaunchKernelGGL(blur_rows_rt_kernel, grid, dim3(256), 0, ctx->stream, src, tmp, rows, cols, gk);
+            hipLaunchKernelGGL(blur_cols_rt_kernel, grid, dim3(256), 0, ctx->stream, (const float*)tmp, src, dst, dog, rows,
+                               cols, gk);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return IMATCH_OK;
+}
+
+static bool kp_less(const KpRec& a, const KpRec& b) {  // KeyPoint12_LessThan (keypoint.cpp)
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.size != b.size) return a.size > b.size;
+    if (a.angle != b.angle) return a.angle < b.angle;
+    if (a.response != b.response) return a.response > b.response;
+    if (a.octave != b.octave) return a.octave > b.octave;
+    return false;
+}
+
+static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static int read_counter(imatch_ctx* ctx, const int* dev, int* host) {
+    HIP_TRY(ctx, hipMemcpyAsync(host, dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return IMATCH_OK;
+}
+
+extern "C" {
+
+int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, const imatch_sift_params* P,
+                        imatch_features** out) {
+    if (!ctx || !img || !P || !out || h <= 0 || w <= 0 || stride < w)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    if (P->n_octave_layers < 1 || P->n_octave_layers + 3 > MAX_LAY)
+        return imatch_set_err(ctx, IMATCH_ESIZE, "nOctaveLayers %d outside 1..%d", P->n_octave_layers, MAX_LAY - 3);
+    if (h > 16384 || w > 16384) return imatch_set_err(ctx, IMATCH_ESIZE, "image larger than 16384 on a side");
+    if (P->clahe && (P->clahe_tiles_x <= 0 || P->clahe_tiles_y <= 0 || P->clahe_tiles_x * P->clahe_tiles_y > 4096))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad CLAHE tile grid");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    const int nl = P->n_octave_layers, first_octave = -1;
+    const int brows = 2 * h, bcols = 2 * w;
+    int n_oct = (int)lrint(log((double)std::min(brows, bcols)) / log(2.) - 2) - first_octave;
+    if (n_oct < 1) n_oct = 1;
+    if (n_oct > MAX_OCT) n_oct = MAX_OCT;
+
+    // ---- arena layout
+    if (!ctx->sift) {
+        ctx->sift = (imatch_sift_state*)calloc(1, sizeof(imatch_sift_state));
+        if (!ctx->sift) return imatch_set_err(ctx, IMATCH_ENOMEM, "host alloc");
+    }
+    imatch_sift_state* S = ctx->sift;
+    PyrTable T;
+    memset(&T, 0, sizeof(T));
+    T.nl = nl;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    const size_t o_img = take((size_t)h * w), o_clahe = take((size_t)h * w);
+    const size_t o_cscr = take((size_t)(P->clahe ? P->clahe_tiles_x * P->clahe_tiles_y : 1) * 1280);
+    const size_t o_up = take((size_t)brows * bcols * 4), o_tmp = take((size_t)brows * bcols * 4);
+    size_t o_g[MAX_OCT][MAX_LAY], o_d[MAX_OCT][MAX_LAY];
+    for (int o = 0; o < n_oct; ++o) {
+        T.rows[o] = o == 0 ? brows : T.rows[o - 1] / 2;
+        T.cols[o] = o == 0 ? bcols : T.cols[o - 1] / 2;
+        if (T.rows[o] < 1 || T.cols[o] < 1) { n_oct = o; break; }
+        const size_t px = (size_t)T.rows[o] * T.cols[o] * 4;
+        for (int i = 0; i < nl + 3; ++i) o_g[o][i] = take(px);
+        for (int i = 0; i < nl + 2; ++i) o_d[o][i] = take(px);
+    }
+    T.n_oct = n_oct;
+    int cap = (int)std::min<size_t>((size_t)brows * bcols / 8 + 16384, (size_t)1 << 28);
+    const size_t o_cnt = take(256);
+    const size_t fixed_end = off;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        off = fixed_end;
+        const size_t o_cand = take((size_t)cap * sizeof(uint2));
+        const size_t o_ref = take((size_t)cap * sizeof(RefinedKp));
+        const size_t o_kp = take((size_t)cap * 2 * sizeof(KpRec));
+        const size_t need = off;
+        if (need > S->arena_bytes) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (S->arena) HIP_TRY(ctx, hipFree(S->arena));
+            S->arena = nullptr;
+            S->arena_bytes = 0;
+            if (hipMalloc((void**)&S->arena, need) != hipSuccess)
+                return imatch_set_err(ctx, IMATCH_ENOMEM, "SIFT arena of %zu bytes", need);
+            S->arena_bytes = need;
+        }
+        char* A = S->arena;
+        for (int o = 0; o < n_oct; ++o) {
+            for (int i = 0; i < nl + 3; ++i) T.gauss[o][i] = (float*)(A + o_g[o][i]);
+            for (int i = 0; i < nl + 2; ++i) T.dog[o][i] = (float*)(A + o_d[o][i]);
+        }
+        S->T = T;
+        S->h = h;
+        S->w = w;
+        uint8_t* d_img = (uint8_t*)(A + o_img);
+        uint8_t* d_clahe = (uint8_t*)(A + o_clahe);
+        float* d_up = (float*)(A + o_up);
+        float* d_tmp = (float*)(A + o_tmp);
+        int* d_cnt = (int*)(A + o_cnt);
+        uint2* d_cand = (uint2*)(A + o_cand);
+        RefinedKp* d_ref = (RefinedKp*)(A + o_ref);
+        KpRec* d_kp = (KpRec*)(A + o_kp);
+
+        // ---- pre-processing + pyramid
+        HIP_TRY(ctx, hipMemcpy2DAsync(d_img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice,
+                                      ctx->stream));
+        const uint8_t* d_src = d_img;
+        if (P->clahe) {
+            int rc = imatch_clahe_dev(ctx, d_img, h, w, w, P->clahe_clip, P->clahe_tiles_x, P->clahe_tiles_y, d_clahe,
+                                      A + o_cscr);
+            if (rc) return rc;
+            d_src = d_clahe;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
+        hipLaunchKernelGGL(upsample2_kernel, dim3((bcols + 63) / 64, (brows + 3) / 4), dim3(256), 0, ctx->stream, d_src, h,
+                           w, w, d_up);
+        const float sig_diff = sqrtf(fmaxf((float)P->sigma * (float)P->sigma - 0.5f * 0.5f * 4, 0.01f));
+        int rc = gaussian_blur(ctx, d_up, T.gauss[0][0], nullptr, d_tmp, brows, bcols, sig_diff);
+        if (rc) return rc;
+        double sig[MAX_LAY];
+        sig[0] = P->sigma;
+        const double kf = pow(2., 1. / nl);
+        for (int i = 1; i < nl + 3; i++) {
+            const double sig_prev = pow(kf, (double)(i - 1)) * P->sigma, sig_total = sig_prev * kf;
+            sig[i] = sqrt(sig_total * sig_total - sig_prev * sig_prev);
+        }
+        const float thr = (float)(int)floor(0.5 * P->contrast_threshold / nl * 255);
+        for (int o = 0; o < n_oct; ++o) {
+            const int rows = T.rows[o], cols = T.cols[o];
+            if (o > 0)
+                hipLaunchKernelGGL(decimate_kernel, dim3((cols + 63) / 64, (rows + 3) / 4), dim3(256), 0, ctx->stream,
+                                   (const float*)T.gauss[o - 1][nl], T.cols[o - 1], T.gauss[o][0], rows, cols);
+            for (int i = 1; i < nl + 3; ++i) {
+                rc = gaussian_blur(ctx, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i]);
+                if (rc) return rc;
+            }
+            if (rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER)
+                hipLaunchKernelGGL(detect_kernel, dim3((cols - 2 * SIFT_IMG_BORDER + 63) / 64, (rows - 2 * SIFT_IMG_BORDER + 3) / 4),
+                                   dim3(256), 0, ctx->stream, T, o, thr, d_cand, cap, d_cnt);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        int n_cand = 0;
+        rc = read_counter(ctx, d_cnt, &n_cand);
+        if (rc) return rc;
+        if (n_cand > cap) {  // rare: grow the lists and run the frame again
+            cap = n_cand + n_cand / 8;
+            continue;
+        }
+        int n_ref = 0, n_kp = 0;
+        if (n_cand > 0) {
+            hipLaunchKernelGGL(refine_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, ctx->stream, T, (const uint2*)d_cand,
+                               n_cand, (float)P->contrast_threshold, (float)P->edge_threshold, (float)P->sigma, d_ref,
+                               d_cnt + 1);
+            HIP_TRY(ctx, hipGetLastError());
+            rc = read_counter(ctx, d_cnt + 1, &n_ref);
+            if (rc) return rc;
+        }
+        if (n_ref > 0) {
+            hipLaunchKernelGGL(orient_kernel, dim3((n_ref + 3) / 4), dim3(256), 0, ctx->stream, T, (const RefinedKp*)d_ref,
+                               n_ref, d_kp, 2 * cap, d_cnt + 2);
+            HIP_TRY(ctx, hipGetLastError());
+            rc = read_counter(ctx, d_cnt + 2, &n_kp);
+            if (rc) return rc;
+            if (n_kp > 2 * cap) {
+                cap = n_kp;
+                continue;
+            }
+        }
+        // ---- removeDuplicatedSorted + first-octave rescale on the host (K records of 24 bytes)
+        std::vector<KpRec> kps((size_t)n_kp);
+        if (n_kp > 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(kps.data(), d_kp, (size_t)n_kp * sizeof(KpRec), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            std::sort(kps.begin(), kps.end(), kp_less);
+            size_t j = 0;
+            for (size_t i = 1; i < kps.size(); ++i) {
+                const KpRec &a = kps[j], &b = kps[i];
+                if (a.x != b.x || a.y != b.y || a.size != b.size || a.angle != b.angle) kps[++j] = kps[i];
+            }
+            kps.resize(j + 1);
+            for (auto& k : kps) {
+                const float scale = 1.f / (float)(1 << -first_octave);
+                k.octave = (k.octave & ~255) | ((k.octave + first_octave) & 255);
+                k.x *= scale; k.y *= scale; k.size *= scale;
+            }
+        }
+        const int K = (int)kps.size();
+        imatch_features* f = nullptr;
+        rc = imatch_features_alloc(ctx, K, &f);
+        if (rc) return rc;
+        f->kp = (float*)malloc(sizeof(float) * 7 * (size_t)std::max(K, 1));
+        for (int i = 0; i < K; ++i) {
+            float* p = f->kp + 7 * (size_t)i;
+            p[0] = kps[i].x; p[1] = kps[i].y; p[2] = kps[i].size; p[3] = kps[i].angle; p[4] = kps[i].response;
+            p[5] = (float)kps[i].octave; p[6] = -1.f;
+        }
+        if (P->clahe) {
+            if (hipMalloc((void**)&f->image, (size_t)h * w) != hipSuccess) {
+                imatch_features_free(f);
+                return imatch_set_err(ctx, IMATCH_ENOMEM, "image copy");
+            }
+            f->img_h = h; f->img_w = w;
+            HIP_TRY(ctx, hipMemcpyAsync(f->image, d_clahe, (size_t)h * w, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        // sorted records and u8 descriptors reuse the candidate / refined lists (no longer needed)
+        KpRec* d_sorted = (KpRec*)d_ref;
+        uint8_t* d_desc = (uint8_t*)d_kp;  // cap*2*24 bytes >= K*128 needs K <= cap*0.375: checked below
+        if ((size_t)K * 128 > (size_t)cap * 2 * sizeof(KpRec) || (size_t)K * sizeof(KpRec) > (size_t)cap * sizeof(RefinedKp)) {
+            imatch_features_free(f);
+            cap = (int)((size_t)K * 3 + 1024);
+            continue;
+        }
+        if (K > 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(d_sorted, kps.data(), (size_t)K * sizeof(KpRec), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(describe_kernel, dim3((K + 3) / 4), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted, K,
+                               first_octave, d_desc);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        rc = imatch_features_pack_u8_dev(ctx, f, d_desc);  // bf16 rows + norms; synchronises (kps stays alive until here)
+        if (rc) { imatch_features_free(f); return rc; }
+        *out = f;
+        return IMATCH_OK;
+    }
+    return imatch_set_err(ctx, IMATCH_ESIZE, "keypoint lists kept overflowing");
+}
+
+int imatch_features_download(const imatch_features* f, float* kp, float* desc) {
+    if (!f) return IMATCH_EINVAL;
+    imatch_ctx* ctx = f->ctx;
+    if (kp) {
+        if (!f->kp && f->n > 0) return imatch_set_err(ctx, IMATCH_EINVAL, "this descriptor set carries no keypoints");
+        if (f->n > 0) memcpy(kp, f->kp, sizeof(float) * 7 * (size_t)f->n);
+    }
+    if (desc && f->n > 0) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int rc = imatch_hs_reserve(ctx, (size_t)f->n * 256);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->hs, f->desc, (size_t)f->n * 256, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const uint16_t* b = (const uint16_t*)ctx->hs;
+        for (size_t i = 0; i < (size_t)f->n * 128; ++i) {
+            const uint32_t u = (uint32_t)b[i] << 16;
+            memcpy(&desc[i], &u, 4);
+        }
+    }
+    return IMATCH_OK;
+}
+
+int imatch_features_image(const imatch_features* f, uint8_t* out, int h, int w) {
+    if (!f || !out) return IMATCH_EINVAL;
+    imatch_ctx* ctx = f->ctx;
+    if (!f->image) return imatch_set_err(ctx, IMATCH_EINVAL, "this descriptor set carries no image");
+    if (h != f->img_h || w != f->img_w) return imatch_set_err(ctx, IMATCH_EINVAL, "image is %dx%d", f->img_w, f->img_h);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out, f->image, (size_t)h * w, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return IMATCH_OK;
+}
+
+int imatch_sift_debug_octaves(imatch_ctx* ctx) { return (ctx && ctx->sift) ? ctx->sift->T.n_oct : 0; }
+
+int imatch_sift_debug_layer(imatch_ctx* ctx, int kind, int o, int i, float* out, int* rows, int* cols) {
+    if (!ctx || !ctx->sift || !ctx->sift->arena) return imatch_set_err(ctx, IMATCH_EINVAL, "no extraction yet");
+    const PyrTable& T = ctx->sift->T;
+    if (o < 0 || o >= T.n_oct || i < 0 || i >= (kind == 0 ? T.nl + 3 : T.nl + 2))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "no such layer");
+    if (rows) *rows = T.rows[o];
+    if (cols) *cols = T.cols[o];
+    if (out) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        const float* p = kind == 0 ? T.gauss[o][i] : T.dog[o][i];
+        HIP_TRY(ctx, hipMemcpyAsync(out, p, (size_t)T.rows[o] * T.cols[o] * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return IMATCH_OK;
+}
+
+}  // extern "C"

@@ -49,3 +49,77 @@ def synth_queries(train, nq, seed=8, noise=6, dup_frac=0.001):
             train[hi] = q[i]
             dup[i] = hi
     return q, src, dup
+
+
+# ---- images (the reference's map.png and flight videos are not in its tree) -------
+def _upsample_bilinear(a, side):
+    n = a.shape[0]
+    t = np.linspace(0, n - 1, side)
+    i0 = np.minimum(t.astype(np.int64), n - 2)
+    f = (t - i0).astype(np.float32)
+    rows = a[i0] * (1 - f)[:, None] + a[i0 + 1] * f[:, None]
+    return rows[:, i0] * (1 - f)[None, :] + rows[:, i0 + 1] * f[None, :]
+
+
+def synth_map(side, seed=1234):
+    """u8 [side,side] orthomap stand-in: 6 octaves of value noise (amplitude ~ 1/f), random filled
+    rectangles and lines ("fields", "roads"), per-pixel Gaussian noise sigma 2."""
+    rng = np.random.default_rng(seed)
+    img = np.zeros((side, side), np.float32)
+    amp = 1.0
+    for o in range(6):
+        n = 4 * (2 ** o) + 1
+        img += amp * _upsample_bilinear(rng.random((n, n), dtype=np.float32), side)
+        amp *= 0.5
+    img = (img - img.min()) / (img.max() - img.min()) * 150 + 50
+    nrect = int(2000 * (side / 2048) ** 2)
+    for _ in range(nrect):
+        w, h = rng.integers(4, 60, size=2)
+        x, y = rng.integers(0, side - 4, size=2)
+        v = rng.uniform(-45, 45)
+        if rng.random() < 0.25:  # a thin "road"
+            if rng.random() < 0.5:
+                w, h = int(rng.integers(60, 300)), int(rng.integers(2, 5))
+            else:
+                w, h = int(rng.integers(2, 5)), int(rng.integers(60, 300))
+        img[y:y + h, x:x + w] += v
+    img += rng.normal(0, 2, size=img.shape).astype(np.float32)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def warp_bilinear(src, H, out_h, out_w):
+    """dst(y,x) = src(H @ (x,y,1)) with bilinear sampling (H maps dst pixels to src pixels)."""
+    ys, xs = np.mgrid[0:out_h, 0:out_w].astype(np.float64)
+    den = H[2, 0] * xs + H[2, 1] * ys + H[2, 2]
+    sx = (H[0, 0] * xs + H[0, 1] * ys + H[0, 2]) / den
+    sy = (H[1, 0] * xs + H[1, 1] * ys + H[1, 2]) / den
+    x0 = np.clip(np.floor(sx).astype(np.int64), 0, src.shape[1] - 2)
+    y0 = np.clip(np.floor(sy).astype(np.int64), 0, src.shape[0] - 2)
+    fx = np.clip(sx - x0, 0, 1)
+    fy = np.clip(sy - y0, 0, 1)
+    s = src.astype(np.float32)
+    top = s[y0, x0] * (1 - fx) + s[y0, x0 + 1] * fx
+    bot = s[y0 + 1, x0] * (1 - fx) + s[y0 + 1, x0 + 1] * fx
+    return top * (1 - fy) + bot * fy
+
+
+def synth_frame(map_img, i, size=(480, 640), scale_range=(0.8, 1.25)):
+    """Frame i cut from the map by a random homography (rotation, scale, slight perspective), with
+    gain/bias/noise. Returns (frame u8, H) where H maps FRAME pixel (x,y,1) to MAP pixel."""
+    rng = np.random.default_rng(1000 + i)
+    h, w = size
+    side = map_img.shape[0]
+    ang = rng.uniform(-np.pi, np.pi)
+    s = rng.uniform(*scale_range)
+    margin = int(0.75 * s * np.hypot(h, w)) + 8
+    cx, cy = rng.uniform(margin, side - margin, size=2)
+    c, sn = np.cos(ang) * s, np.sin(ang) * s
+    A = np.array([[c, -sn, 0], [sn, c, 0], [0, 0, 1.0]])
+    P = np.eye(3)
+    P[2, 0], P[2, 1] = rng.uniform(-1e-4, 1e-4, size=2)
+    T0 = np.array([[1, 0, -w / 2], [0, 1, -h / 2], [0, 0, 1.0]])
+    T1 = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1.0]])
+    H = T1 @ A @ P @ T0
+    f = warp_bilinear(map_img, H, h, w)
+    f = f * rng.uniform(0.8, 1.2) + rng.uniform(-15, 15) + rng.normal(0, 3, size=f.shape)
+    return np.clip(np.rint(f), 0, 255).astype(np.uint8), H / H[2, 2]

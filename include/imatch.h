@@ -45,6 +45,12 @@ const char* imatch_last_error(const imatch_ctx* ctx);
 void* imatch_stream(imatch_ctx* ctx);
 int imatch_synchronize(imatch_ctx* ctx);
 
+/* Measurement hook (no reference counterpart; bench.py's roofline block): with profiling on, the
+ * kNN launcher brackets its MFMA kernel with HIP events on the context's stream;
+ * imatch_knn2_kernel_ms waits for the last launch and returns its duration. */
+int imatch_set_profiling(imatch_ctx* ctx, int on);
+int imatch_knn2_kernel_ms(imatch_ctx* ctx, float* ms);
+
 /* Descriptor sets resident in HBM ----------------------------------------- */
 /* Replaces cv2.cuda_GpuMat(descriptors) (MF:187-188), but the set outlives the call:
  * rows are stored as bf16 [n_pad][128] (exact for 0..255 integers) plus f32 squared norms. */
@@ -56,6 +62,45 @@ int64_t imatch_features_count(const imatch_features* f);
 /* 1 when every descriptor value of the set is an integer in 0..255 (kNN is then bit-exact), else 0. */
 int imatch_features_is_integral(const imatch_features* f);
 void imatch_features_free(imatch_features* f);
+
+/* Pre-processing ----------------------------------------------------------- */
+/* Replaces cv2.createCLAHE(clipLimit, tileGridSize=(tiles_x,tiles_y)).apply(img) (MF:200,203; also
+ * normalize_images MF:324-326). 8-bit gray, `stride` bytes per row; out is [h][w] contiguous. */
+int imatch_clahe(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, double clip_limit,
+                 int tiles_x, int tiles_y, uint8_t* out);
+/* Replaces cv2.resize(img, (dw, dh), interpolation=cv2.INTER_AREA) as utils.resize_img calls it
+ * (utils.py:17-22; callers MF:165-175,308-311). Shrinking only (dh <= h, dw <= w). */
+int imatch_resize_area(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride,
+                       uint8_t* out, int dh, int dw);
+
+/* SIFT extraction ---------------------------------------------------------- */
+typedef struct imatch_sift_params {
+    int n_octave_layers;       /* nOctaveLayers_sift   (MF:31), OpenCV default 3 */
+    double contrast_threshold; /* contrastThreshold_sift (MF:32), 0.04 */
+    double edge_threshold;     /* edgeThreshold_sift   (MF:33), 10 */
+    double sigma;              /* sigma_sift           (MF:34), 1.6 */
+    int clahe;                 /* 1: apply CLAHE first, as find_kp_dp does (MF:200-203) */
+    double clahe_clip;         /* 30.0 */
+    int clahe_tiles_x, clahe_tiles_y; /* 8, 8 */
+} imatch_sift_params;
+
+/* Replaces find_kp_dp's body (MF:199-221 with the SIFT call of MF:205-209):
+ * [CLAHE ->] SIFT_create(0, nOctaveLayers, contrastThreshold, edgeThreshold, sigma)
+ * .detectAndCompute(img, None). The result is a descriptor set resident in HBM (usable directly by
+ * imatch_knn2) that also carries the keypoints and, with clahe=1, the equalised image. */
+int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride,
+                        const imatch_sift_params* params, imatch_features** out);
+/* kp: [K][7] = x, y, size, angle, response, octave, class_id (cv2.KeyPoint fields, OpenCV's final
+ * order: sorted and de-duplicated as KeyPointsFilter::removeDuplicatedSorted leaves them);
+ * desc: [K][128] f32, integer valued 0..255. Either pointer may be null. */
+int imatch_features_download(const imatch_features* f, float* kp, float* desc);
+/* The image find_kp_dp returns (MF:221): the CLAHE output, [h][w] u8. */
+int imatch_features_image(const imatch_features* f, uint8_t* out, int h, int w);
+/* Test hook (no reference counterpart): copies one pyramid layer of the context's LAST extraction
+ * to the host. kind 0 = Gaussian layer i of octave o, 1 = DoG layer. rows/cols receive its size;
+ * out may be null to query the size only. */
+int imatch_sift_debug_layer(imatch_ctx* ctx, int kind, int o, int i, float* out, int* rows, int* cols);
+int imatch_sift_debug_octaves(imatch_ctx* ctx);
 
 /* Brute-force kNN, k = 2 --------------------------------------------------- */
 /* Replaces cv2.BFMatcher(cv2.NORM_L2).knnMatch(q, t, k=2) (MF:182-183) and the cv2.cuda

@@ -80,3 +80,112 @@ def ratio(idx, dist, r):
     gd = np.empty(nq, np.float32)
     g = lib().oracle_ratio(_p(idx, _i32p), _p(dist, _f32p), nq, float(r), _p(gq, _i32p), _p(gt, _i32p), _p(gd, _f32p))
     return gq[:g].copy(), gt[:g].copy(), gd[:g].copy()
+
+
+# ---- CLAHE / INTER_AREA / SIFT (sift_oracle.c) ---------------------------------------------
+def _declare_sift(L):
+    c_int, c_double = ctypes.c_int, ctypes.c_double
+    L.oracle_clahe.argtypes = [_u8p, c_int, c_int, c_double, c_int, c_int, _u8p]
+    L.oracle_clahe.restype = None
+    L.oracle_resize_area.argtypes = [_u8p, c_int, c_int, _u8p, c_int, c_int]
+    L.oracle_resize_area.restype = c_int
+    L.oracle_gauss_kernel.argtypes = [c_double, _f32p]
+    L.oracle_gauss_kernel.restype = c_int
+    L.oracle_gauss_blur.argtypes = [_f32p, c_int, c_int, c_double, _f32p]
+    L.oracle_gauss_blur.restype = None
+    L.oracle_sift_run.argtypes = [_u8p, c_int, c_int, c_int, c_double, c_double, c_double, c_int]
+    L.oracle_sift_run.restype = ctypes.c_void_p
+    L.oracle_sift_free.argtypes = [ctypes.c_void_p]
+    L.oracle_sift_free.restype = None
+    L.oracle_sift_count.argtypes = [ctypes.c_void_p]
+    L.oracle_sift_count.restype = c_int
+    L.oracle_sift_octaves.argtypes = [ctypes.c_void_p]
+    L.oracle_sift_octaves.restype = c_int
+    L.oracle_sift_octave_size.argtypes = [ctypes.c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    L.oracle_sift_octave_size.restype = None
+    L.oracle_sift_get.argtypes = [ctypes.c_void_p, _f32p, _f32p]
+    L.oracle_sift_get.restype = None
+    L.oracle_sift_layer.argtypes = [ctypes.c_void_p, c_int, c_int, c_int, _f32p]
+    L.oracle_sift_layer.restype = c_int
+
+
+_orig_declare = _declare
+
+
+def _declare(L):  # noqa: F811
+    _orig_declare(L)
+    _declare_sift(L)
+
+
+def clahe(img, clip_limit=30.0, tiles=(8, 8)):
+    """cv2.createCLAHE(clipLimit, tileGridSize=tiles).apply(img) for uint8 gray."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(img)
+    lib().oracle_clahe(_p(img, _u8p), img.shape[0], img.shape[1], float(clip_limit), int(tiles[0]), int(tiles[1]),
+                       _p(out, _u8p))
+    return out
+
+
+def resize_area(img, dsize):
+    """cv2.resize(img, dsize=(width, height), interpolation=cv2.INTER_AREA), shrink only."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    dw, dh = int(dsize[0]), int(dsize[1])
+    out = np.empty((dh, dw), np.uint8)
+    rc = lib().oracle_resize_area(_p(img, _u8p), img.shape[0], img.shape[1], _p(out, _u8p), dh, dw)
+    if rc != 0:
+        raise ValueError("oracle.resize_area restates shrinking only")
+    return out
+
+
+def gauss_kernel(sigma):
+    k = np.zeros(64, np.float32)
+    n = lib().oracle_gauss_kernel(float(sigma), _p(k, _f32p))
+    return k[:n].copy()
+
+
+def gauss_blur(img, sigma):
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    out = np.empty_like(img)
+    lib().oracle_gauss_blur(_p(img, _f32p), img.shape[0], img.shape[1], float(sigma), _p(out, _f32p))
+    return out
+
+
+class SiftResult:
+    """keypoints [K,7] = (x, y, size, angle, response, octave, class_id) in OpenCV's final order,
+    descriptors [K,128] float32 (integer valued), and optionally the pyramids."""
+
+    def __init__(self, kp, desc, gauss=None, dog=None):
+        self.kp, self.desc, self.gauss, self.dog = kp, desc, gauss, dog
+
+
+def sift(img, n_octave_layers=3, contrast_threshold=0.04, edge_threshold=10.0, sigma=1.6, keep_pyramid=False):
+    """cv2.SIFT_create(0, nOctaveLayers, contrastThreshold, edgeThreshold, sigma).detectAndCompute(img, None)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    L = lib()
+    h = L.oracle_sift_run(_p(img, _u8p), img.shape[0], img.shape[1], int(n_octave_layers), float(contrast_threshold),
+                          float(edge_threshold), float(sigma), 1 if keep_pyramid else 0)
+    try:
+        n = L.oracle_sift_count(h)
+        kp = np.empty((n, 7), np.float32)
+        desc = np.empty((n, 128), np.float32)
+        L.oracle_sift_get(h, _p(kp, _f32p), _p(desc, _f32p))
+        gauss = dog = None
+        if keep_pyramid:
+            gauss, dog = [], []
+            for o in range(L.oracle_sift_octaves(h)):
+                r, c = ctypes.c_int(), ctypes.c_int()
+                L.oracle_sift_octave_size(h, o, ctypes.byref(r), ctypes.byref(c))
+                g, d = [], []
+                for i in range(n_octave_layers + 3):
+                    a = np.empty((r.value, c.value), np.float32)
+                    L.oracle_sift_layer(h, 0, o, i, _p(a, _f32p))
+                    g.append(a)
+                for i in range(n_octave_layers + 2):
+                    a = np.empty((r.value, c.value), np.float32)
+                    L.oracle_sift_layer(h, 1, o, i, _p(a, _f32p))
+                    d.append(a)
+                gauss.append(g)
+                dog.append(d)
+        return SiftResult(kp, desc, gauss, dog)
+    finally:
+        L.oracle_sift_free(h)

@@ -1,0 +1,144 @@
+"""GPU parity: CLAHE, INTER_AREA and SIFT through the C-ABI vs the CPU oracle.
+
+Bars (BASELINE.json north_star): byte stages (CLAHE, resize) bit-exact; the f32 pyramid is bit-exact
+because both sides use the same fma order; keypoints within 0.5 px for >= 99 % of the oracle's
+keypoints; descriptors within L2 <= 16 (of norm 512; a few +-1 LSB flips from exp/atan2 and parallel
+summation order) for >= 99 % of matched keypoints."""
+import numpy as np
+import pytest
+
+import oracle
+import image_matching_amd as im
+from image_matching_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DESC_L2_TOL = 16.0
+KP_TOL_PX = 0.5
+
+
+@pytest.fixture(scope="module")
+def small_map():
+    return synth.synth_map(768, seed=99)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (240, 320), (243, 325), (97, 131), (64, 64), (1000, 700)])
+def test_clahe_bit_exact(ctx, small_map, shape):
+    img = small_map[:shape[0], :shape[1]] if shape[0] <= 768 and shape[1] <= 768 else np.tile(small_map, (2, 1))[:shape[0], :shape[1]]
+    got = ctx.clahe(img)
+    want = oracle.clahe(img)
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_clahe_strided_view_and_flat_image(ctx, small_map):
+    view = small_map[10:310, 20:420]  # non-contiguous rows
+    assert np.array_equal(ctx.clahe(view), oracle.clahe(view))
+    flat = np.full((120, 160), 77, np.uint8)
+    assert np.array_equal(ctx.clahe(flat), oracle.clahe(flat))
+
+
+@pytest.mark.parametrize("shape,dsize", [((720, 1280), (640, 360)), ((480, 640), (427, 320)), ((768, 768), (500, 333)),
+                                         ((300, 500), (499, 299)), ((600, 600), (200, 200)), ((97, 131), (17, 13)),
+                                         ((480, 640), (640, 480))])
+def test_resize_area_bit_exact(ctx, small_map, shape, dsize):
+    img = np.tile(small_map, (1, 2))[:shape[0], :shape[1]]
+    got = ctx.resize_area(img, dsize)
+    want = oracle.resize_area(img, dsize)
+    assert got.shape == want.shape == (dsize[1], dsize[0])
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_resize_enlarge_is_an_error(ctx, small_map):
+    with pytest.raises(im.ImatchError):
+        ctx.resize_area(small_map[:100, :100], (200, 200))
+
+
+@pytest.mark.parametrize("shape", [(240, 320), (201, 333), (64, 96)])
+def test_pyramid_bit_exact(ctx, small_map, shape):
+    img = small_map[:shape[0], :shape[1]]
+    want = oracle.sift(img, keep_pyramid=True)
+    f = ctx.sift_extract(img, im.SiftParams(clahe=False))
+    assert ctx.sift_debug_octaves() == len(want.gauss)
+    for o in range(len(want.gauss)):
+        for i in range(6):
+            got = ctx.sift_debug_layer(0, o, i)
+            assert got.shape == want.gauss[o][i].shape
+            assert np.array_equal(got, want.gauss[o][i]), ("gauss", o, i, float(np.abs(got - want.gauss[o][i]).max()))
+        for i in range(5):
+            got = ctx.sift_debug_layer(1, o, i)
+            assert np.array_equal(got, want.dog[o][i]), ("dog", o, i)
+    f.free()
+
+
+def _match_keypoints(kp_g, kp_o):
+    """For every oracle keypoint the nearest GPU keypoint with the same octave/layer word and an angle
+    within 1 degree; returns (index into GPU or -1, distance)."""
+    from scipy.spatial import cKDTree
+    tree = cKDTree(kp_g[:, :2])
+    idx = np.full(len(kp_o), -1)
+    dist = np.full(len(kp_o), np.inf)
+    for i, k in enumerate(kp_o):
+        for j in tree.query_ball_point(k[:2], KP_TOL_PX):
+            g = kp_g[j]
+            da = abs(g[3] - k[3])
+            da = min(da, 360 - da)
+            if (int(g[5]) & 0xffff) == (int(k[5]) & 0xffff) and da < 1.0:
+                d = float(np.hypot(*(g[:2] - k[:2])))
+                if d < dist[i]:
+                    idx[i], dist[i] = j, d
+    return idx, dist
+
+
+@pytest.mark.parametrize("shape,clahe", [((480, 640), True), ((240, 320), False), ((333, 517), True)])
+def test_keypoints_and_descriptors(ctx, small_map, shape, clahe):
+    img = small_map[:shape[0], :shape[1]]
+    pre = oracle.clahe(img) if clahe else img
+    want = oracle.sift(pre)
+    f = ctx.sift_extract(img, im.SiftParams(clahe=clahe))
+    kp, desc = f.download()
+    if clahe:
+        assert np.array_equal(f.image(*shape), pre)
+    assert len(want.kp) > 100
+    # integer-valued descriptors, SIFT-normalised
+    assert np.array_equal(desc, np.rint(desc)) and desc.min() >= 0 and desc.max() <= 255
+    # OpenCV's final order: sorted by (x, y, -size, angle)
+    key = np.lexsort((kp[:, 3], -kp[:, 2], kp[:, 1], kp[:, 0]))
+    assert np.array_equal(key, np.arange(len(kp)))
+    idx, dist = _match_keypoints(kp, want.kp)
+    found = idx >= 0
+    assert found.mean() >= 0.99, (found.mean(), len(kp), len(want.kp))
+    assert abs(len(kp) - len(want.kp)) <= 0.01 * len(want.kp) + 2
+    l2 = np.linalg.norm(desc[idx[found]] - want.desc[found], axis=1)
+    assert (l2 <= DESC_L2_TOL).mean() >= 0.99, (float(np.percentile(l2, 99)), float(l2.max()))
+    print("kp %d/%d matched %.4f  exact-pos %.4f  desc L2 p50 %.2f p99 %.2f max %.2f  identical %.3f" % (
+        len(kp), len(want.kp), found.mean(), (dist[found] == 0).mean(), np.median(l2), np.percentile(l2, 99), l2.max(),
+        (l2 == 0).mean()))
+    f.free()
+
+
+def test_degenerate_images(ctx):
+    flat = np.full((100, 120), 128, np.uint8)
+    f = ctx.sift_extract(flat)
+    assert len(f) == 0
+    kp, desc = f.download()
+    assert kp.shape == (0, 7) and desc.shape == (0, 128)
+    tiny = (np.arange(12 * 9) % 251).astype(np.uint8).reshape(9, 12)
+    f2 = ctx.sift_extract(tiny, im.SiftParams(clahe=False))
+    assert len(f2) == len(oracle.sift(tiny).kp)
+
+
+def test_extract_is_deterministic(ctx, small_map):
+    img = small_map[:300, :400]
+    a = ctx.sift_extract(img).download()
+    b = ctx.sift_extract(img).download()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_non_default_params(ctx, small_map):
+    img = small_map[:200, :260]
+    want = oracle.sift(img, n_octave_layers=4, contrast_threshold=0.03, edge_threshold=12, sigma=1.4)
+    f = ctx.sift_extract(img, im.SiftParams(n_octave_layers=4, contrast_threshold=0.03, edge_threshold=12, sigma=1.4,
+                                            clahe=False))
+    kp, desc = f.download()
+    idx, dist = _match_keypoints(kp, want.kp)
+    assert (idx >= 0).mean() >= 0.99
