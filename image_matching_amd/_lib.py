@@ -61,6 +61,8 @@ SIGNATURES = {
     "imatch_sift_debug_layer": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
                                                ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "imatch_sift_debug_octaves": (ctypes.c_int, [c_vp]),
+    "imatch_homography": (ctypes.c_int, [c_vp, c_f32p, c_f32p, ctypes.c_int, ctypes.c_double, ctypes.c_uint64,
+                                         ctypes.POINTER(ctypes.c_double), c_u8p, ctypes.POINTER(ctypes.c_int)]),
     "imatch_knn2": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32p, c_f32p]),
     "imatch_knn2_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
     "imatch_merge_top2_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, c_vp]),
@@ -268,6 +270,27 @@ class Context:
 
     def sift_debug_octaves(self):
         return self.lib.imatch_sift_debug_octaves(self._h)
+
+    # -- homography ------------------------------------------------------------------------
+    def homography(self, src, dst, thr=0.1, seed=0):
+        """cv2.findHomography(src, dst, cv2.USAC_MAGSAC, thr) -> (H float64 [3,3], mask uint8 [n,1]) or
+        (None, None) when no model exists."""
+        src = np.ascontiguousarray(np.asarray(src, dtype=np.float32).reshape(-1, 2))
+        dst = np.ascontiguousarray(np.asarray(dst, dtype=np.float32).reshape(-1, 2))
+        if src.shape != dst.shape:
+            raise ValueError("src and dst must have the same number of points")
+        n = src.shape[0]
+        H = np.zeros((3, 3), np.float64)
+        mask = np.zeros((max(n, 1), 1), np.uint8)
+        found = ctypes.c_int(0)
+        with self.lock:
+            self._check(self.lib.imatch_homography(self._h, _ptr(src, c_f32p), _ptr(dst, c_f32p), n, float(thr),
+                                                   ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                                   H.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                   _ptr(mask, c_u8p), ctypes.byref(found)))
+        if not found.value:
+            return None, None
+        return H, mask[:n]
 
     # -- kNN ---------------------------------------------------------------------------
     def knn2(self, q, t):

@@ -1,0 +1,230 @@
+// Robust homography: replaces cv2.findHomography(src, dst, cv2.USAC_MAGSAC, 0.1)
+// (reference match_finder.py:233). OpenCV's USAC sampler is sequential; here all hypotheses are
+// generated and scored at once: one thread per hypothesis builds a 4-point homography in closed
+// form (two projective bases, f64) and scores it against every correspondence (MSAC sum, f32);
+// a 64-bit atomicMax on (score bits, ~h) picks the winner deterministically. The winner is refit
+// on the host (Tukey-weighted least squares + Gauss-Newton, f64, a few hundred points).
+#include "common.h"
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
+
+#define HOMO_HYPOTHESES 4096
+#define HOMO_TAU_FLOOR 3.0
+#define HOMO_IRLS 6
+#define HOMO_GN 4
+
+__host__ __device__ static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__host__ __device__ static inline bool sample4(uint64_t seed, uint32_t h, int n, int idx[4]) {
+    int k = 0;
+    for (uint32_t cnt = 0; cnt < 32 && k < 4; ++cnt) {
+        const uint64_t u = splitmix64(seed + 0x9E3779B97F4A7C15ull * ((uint64_t)h * 32 + cnt + 1));
+        const int j = (int)(u % (uint64_t)n);
+        bool dup = false;
+        for (int t = 0; t < k; ++t) dup |= idx[t] == j;
+        if (!dup) idx[k++] = j;
+    }
+    return k == 4;
+}
+
+// A maps e1, e2, e3, (1,1,1) to the four points; false when a triple is near-collinear
+__host__ __device__ static inline bool proj_basis(const double x[4], const double y[4], double A[9], int& sgn) {
+    const double c0 = y[1] - y[2], c1 = y[2] - y[0], c2 = y[0] - y[1];
+    const double det = x[0] * c0 + x[1] * c1 + x[2] * c2;
+    const double l0 = (y[1] - y[2]) * x[3] + (x[2] - x[1]) * y[3] + (x[1] * y[2] - x[2] * y[1]);
+    const double l1 = (y[2] - y[0]) * x[3] + (x[0] - x[2]) * y[3] + (x[2] * y[0] - x[0] * y[2]);
+    const double l2 = (y[0] - y[1]) * x[3] + (x[1] - x[0]) * y[3] + (x[0] * y[1] - x[1] * y[0]);
+    const double eps = 1e-6;
+    if (fabs(det) < eps || fabs(l0) < eps || fabs(l1) < eps || fabs(l2) < eps) return false;
+    sgn = (det > 0 ? 1 : 0) | (l0 > 0 ? 2 : 0) | (l1 > 0 ? 4 : 0) | (l2 > 0 ? 8 : 0);
+    const double a = l0 / det, b = l1 / det, c = l2 / det;
+    A[0] = a * x[0]; A[1] = b * x[1]; A[2] = c * x[2];
+    A[3] = a * y[0]; A[4] = b * y[1]; A[5] = c * y[2];
+    A[6] = a;        A[7] = b;        A[8] = c;
+    return true;
+}
+
+__host__ __device__ static inline void mul3(const double A[9], const double B[9], double C[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// pts: double [4][n] = sx, sy, dx, dy in normalised coordinates
+__host__ __device__ static inline bool hypothesis(const double* pts, int n, uint64_t seed, uint32_t h, double H[9]) {
+    int idx[4];
+    if (!sample4(seed, h, n, idx)) return false;
+    double xs[4], ys[4], xd[4], yd[4], A[9], B[9], Ai[9];
+    for (int k = 0; k < 4; ++k) {
+        xs[k] = pts[idx[k]]; ys[k] = pts[n + idx[k]]; xd[k] = pts[2 * n + idx[k]]; yd[k] = pts[3 * n + idx[k]];
+    }
+    int s1, s2;
+    if (!proj_basis(xs, ys, A, s1) || !proj_basis(xd, yd, B, s2)) return false;
+    if (s1 != s2) return false;  // a triple changes orientation: not a physical view
+    Ai[0] = A[4] * A[8] - A[5] * A[7]; Ai[1] = A[2] * A[7] - A[1] * A[8]; Ai[2] = A[1] * A[5] - A[2] * A[4];
+    Ai[3] = A[5] * A[6] - A[3] * A[8]; Ai[4] = A[0] * A[8] - A[2] * A[6]; Ai[5] = A[2] * A[3] - A[0] * A[5];
+    Ai[6] = A[3] * A[7] - A[4] * A[6]; Ai[7] = A[1] * A[6] - A[0] * A[7]; Ai[8] = A[0] * A[4] - A[1] * A[3];
+    mul3(B, Ai, H);
+    double m = 0;
+    for (int k = 0; k < 9; ++k) m = fmax(m, fabs(H[k]));
+    if (!(m > 0) || !isfinite(m)) return false;
+    for (int k = 0; k < 9; ++k) H[k] /= m;
+    return true;
+}
+
+__global__ void __launch_bounds__(256)
+homography_score_kernel(const double* __restrict__ pts, const float* __restrict__ fpts, int n, uint64_t seed,
+                        float inv_tau2, unsigned long long* __restrict__ best) {
+    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= HOMO_HYPOTHESES) return;
+    double H[9];
+    if (!hypothesis(pts, n, seed, h, H)) return;
+    float Hf[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Hf[k] = (float)H[k];
+    const float *sx = fpts, *sy = fpts + n, *dx = fpts + 2 * n, *dy = fpts + 3 * n;
+    float score = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float w = Hf[6] * sx[i] + Hf[7] * sy[i] + Hf[8];
+        const float u = (Hf[0] * sx[i] + Hf[1] * sy[i] + Hf[2]) / w;
+        const float v = (Hf[3] * sx[i] + Hf[4] * sy[i] + Hf[5]) / w;
+        const float ex = u - dx[i], ey = v - dy[i];
+        const float t = 1.f - (ex * ex + ey * ey) * inv_tau2;
+        if (t > 0.f) score += t;
+    }
+    // scores are >= 0: their bit patterns order like the floats; ties go to the lower h
+    const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (0xFFFFFFFFu - h);
+    atomicMax(best, key);
+}
+
+static void hartley(const float* p, int n, double T[3]) {
+    double cx = 0, cy = 0;
+    for (int i = 0; i < n; ++i) { cx += p[2 * i]; cy += p[2 * i + 1]; }
+    cx /= n; cy /= n;
+    double md = 0;
+    for (int i = 0; i < n; ++i) md += sqrt((p[2 * i] - cx) * (p[2 * i] - cx) + (p[2 * i + 1] - cy) * (p[2 * i + 1] - cy));
+    md /= n;
+    T[0] = md > 1e-12 ? sqrt(2.0) / md : 1.0;
+    T[1] = cx; T[2] = cy;
+}
+
+static bool solve8(double A[8][9]) {
+    for (int c = 0; c < 8; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 8; ++r) if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+        if (fabs(A[p][c]) < 1e-14) return false;
+        if (p != c) for (int k = 0; k < 9; ++k) std::swap(A[c][k], A[p][k]);
+        const double inv = 1.0 / A[c][c];
+        for (int k = c; k < 9; ++k) A[c][k] *= inv;
+        for (int r = 0; r < 8; ++r) if (r != c) {
+            const double f = A[r][c];
+            if (f != 0) for (int k = c; k < 9; ++k) A[r][k] -= f * A[c][k];
+        }
+    }
+    return true;
+}
+
+// Tukey-weighted least squares rounds, then Gauss-Newton on the forward transfer error
+static bool refit(const double* P, int n, double tau2, double h8[8]) {
+    const double *sx = P, *sy = P + n, *dx = P + 2 * n, *dy = P + 3 * n;
+    std::vector<double> w((size_t)n, 0.0);
+    for (int it = 0; it < HOMO_IRLS + HOMO_GN; ++it) {
+        double N[8][9];
+        memset(N, 0, sizeof(N));
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            const double x = sx[i], y = sy[i], u = dx[i], v = dy[i];
+            const double ww = h8[6] * x + h8[7] * y + 1.0;
+            const double pu = (h8[0] * x + h8[1] * y + h8[2]) / ww, pv = (h8[3] * x + h8[4] * y + h8[5]) / ww;
+            const double ex = u - pu, ey = v - pv, e2 = ex * ex + ey * ey;
+            if (it <= HOMO_IRLS) {  // frozen during the remaining Gauss-Newton steps
+                const double t = 1.0 - e2 / tau2;
+                w[i] = t > 0 ? t * t : 0.0;
+            }
+            if (w[i] <= 0) continue;
+            ++cnt;
+            double r1[9], r2[9];
+            if (it < HOMO_IRLS) {
+                r1[0] = x; r1[1] = y; r1[2] = 1; r1[3] = 0; r1[4] = 0; r1[5] = 0; r1[6] = -x * u; r1[7] = -y * u; r1[8] = u;
+                r2[0] = 0; r2[1] = 0; r2[2] = 0; r2[3] = x; r2[4] = y; r2[5] = 1; r2[6] = -x * v; r2[7] = -y * v; r2[8] = v;
+            } else {
+                const double iw = 1.0 / ww;
+                r1[0] = x * iw; r1[1] = y * iw; r1[2] = iw; r1[3] = 0; r1[4] = 0; r1[5] = 0; r1[6] = -x * pu * iw; r1[7] = -y * pu * iw; r1[8] = ex;
+                r2[0] = 0; r2[1] = 0; r2[2] = 0; r2[3] = x * iw; r2[4] = y * iw; r2[5] = iw; r2[6] = -x * pv * iw; r2[7] = -y * pv * iw; r2[8] = ey;
+            }
+            for (int a = 0; a < 8; ++a) {
+                if (r1[a] != 0) for (int b = 0; b < 9; ++b) N[a][b] += w[i] * r1[a] * r1[b];
+                if (r2[a] != 0) for (int b = 0; b < 9; ++b) N[a][b] += w[i] * r2[a] * r2[b];
+            }
+        }
+        if (cnt < 4 || !solve8(N)) return it > 0;
+        if (it < HOMO_IRLS) for (int k = 0; k < 8; ++k) h8[k] = N[k][8];
+        else for (int k = 0; k < 8; ++k) h8[k] += N[k][8];
+    }
+    return true;
+}
+
+extern "C" int imatch_homography(imatch_ctx* ctx, const float* src, const float* dst, int n, double thr, uint64_t seed,
+                                 double* H_out, uint8_t* mask, int* found) {
+    if (!ctx || !found || !H_out || n < 0 || (n > 0 && (!src || !dst))) return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    *found = 0;
+    if (mask && n > 0) memset(mask, 0, (size_t)n);
+    if (n < 4) return IMATCH_OK;  // cv2.findHomography returns (None, None)
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double Ts[3], Td[3];
+    hartley(src, n, Ts);
+    hartley(dst, n, Td);
+    const size_t dbytes = sizeof(double) * 4 * (size_t)n, fbytes = sizeof(float) * 4 * (size_t)n;
+    int rc = imatch_hs_reserve(ctx, dbytes + fbytes + 64);
+    if (rc) return rc;
+    rc = imatch_ws_reserve(ctx, dbytes + fbytes + 256);
+    if (rc) return rc;
+    double* P = (double*)ctx->hs;
+    float* F = (float*)((char*)ctx->hs + dbytes);
+    for (int i = 0; i < n; ++i) {
+        P[i] = Ts[0] * (src[2 * i] - Ts[1]); P[n + i] = Ts[0] * (src[2 * i + 1] - Ts[2]);
+        P[2 * n + i] = Td[0] * (dst[2 * i] - Td[1]); P[3 * n + i] = Td[0] * (dst[2 * i + 1] - Td[2]);
+    }
+    for (int i = 0; i < 4 * n; ++i) F[i] = (float)P[i];
+    char* dev = (char*)ctx->ws;
+    unsigned long long* d_best = (unsigned long long*)(dev + dbytes + fbytes);
+    HIP_TRY(ctx, hipMemcpyAsync(dev, ctx->hs, dbytes + fbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_best, 0, 8, ctx->stream));
+    const double tau = fmax(thr, HOMO_TAU_FLOOR) * Td[0];
+    hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / 256), dim3(256), 0, ctx->stream, (const double*)dev,
+                       (const float*)(dev + dbytes), n, seed, (float)(1.0 / (tau * tau)), d_best);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long key = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&key, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (key == 0) return IMATCH_OK;  // no non-degenerate sample
+    const uint32_t h = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+    double Hb[9];
+    if (!hypothesis(P, n, seed, h, Hb) || fabs(Hb[8]) <= 1e-9) return IMATCH_OK;
+    double h8[8];
+    for (int k = 0; k < 8; ++k) h8[k] = Hb[k] / Hb[8];
+    if (!refit(P, n, tau * tau, h8)) return IMATCH_OK;
+    const double Hn[9] = {h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7], 1.0};
+    const double TS[9] = {Ts[0], 0, -Ts[0] * Ts[1], 0, Ts[0], -Ts[0] * Ts[2], 0, 0, 1};
+    const double TDi[9] = {1.0 / Td[0], 0, Td[1], 0, 1.0 / Td[0], Td[2], 0, 0, 1};
+    double t[9], H[9];
+    mul3(Hn, TS, t);
+    mul3(TDi, t, H);
+    if (fabs(H[8]) < 1e-12) return IMATCH_OK;
+    for (int k = 0; k < 9; ++k) H_out[k] = H[k] / H[8];
+    if (mask)
+        for (int i = 0; i < n; ++i) {
+            const double x = src[2 * i], y = src[2 * i + 1];
+            const double ww = H_out[6] * x + H_out[7] * y + 1.0;
+            const double ex = (H_out[0] * x + H_out[1] * y + H_out[2]) / ww - dst[2 * i];
+            const double ey = (H_out[3] * x + H_out[4] * y + H_out[5]) / ww - dst[2 * i + 1];
+            mask[i] = (ex * ex + ey * ey <= thr * thr) ? 1 : 0;
+        }
+    *found = 1;
+    return IMATCH_OK;
+}

@@ -125,6 +125,16 @@ int imatch_merge_top2_dev(imatch_ctx* ctx, const int32_t* in4_dev, int n_lists, 
 int imatch_ratio_dev(imatch_ctx* ctx, const int32_t* out4_dev, int64_t nq, double ratio,
                      int32_t* good_q, int32_t* good_t, float* good_d, int64_t* n_good);
 
+/* Robust homography -------------------------------------------------------- */
+/* Replaces cv2.findHomography(src_pts, dst_pts, cv2.USAC_MAGSAC, thr) (MF:233). src/dst are f32
+ * [n][2] (the reference passes kp[].pt gathered as float32, MF:231-232). On success *found = 1,
+ * H is row-major 3x3 with H[8] = 1 and mask[i] = 1 where the forward reprojection error is <= thr.
+ * *found = 0 (H untouched, mask zero) when there is no model: n < 4 or only degenerate samples --
+ * the case in which cv2 returns (None, None). All hypotheses are scored on the GPU at once;
+ * `seed` makes the sampling reproducible. mask may be null. */
+int imatch_homography(imatch_ctx* ctx, const float* src, const float* dst, int n, double thr,
+                      uint64_t seed, double* H, uint8_t* mask, int* found);
+
 #ifdef __cplusplus
 }
 #endif

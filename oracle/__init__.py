@@ -189,3 +189,32 @@ def sift(img, n_octave_layers=3, contrast_threshold=0.04, edge_threshold=10.0, s
         return SiftResult(kp, desc, gauss, dog)
     finally:
         L.oracle_sift_free(h)
+
+
+# ---- homography (homography_oracle.c) -------------------------------------------------------
+def _declare_homography(L):
+    L.oracle_homography.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_double, ctypes.c_uint64,
+                                    ctypes.POINTER(ctypes.c_double), _u8p]
+    L.oracle_homography.restype = ctypes.c_int
+
+
+_declare_before_homography = _declare
+
+
+def _declare(L):  # noqa: F811
+    _declare_before_homography(L)
+    _declare_homography(L)
+
+
+def homography(src, dst, thr=0.1, seed=0):
+    """Spec H' estimator -> (H [3,3] float64, mask uint8 [n,1]) or (None, None)."""
+    src = np.ascontiguousarray(np.asarray(src, dtype=np.float32).reshape(-1, 2))
+    dst = np.ascontiguousarray(np.asarray(dst, dtype=np.float32).reshape(-1, 2))
+    n = src.shape[0]
+    H = np.zeros((3, 3), np.float64)
+    mask = np.zeros((max(n, 1), 1), np.uint8)
+    ok = lib().oracle_homography(_p(src, _f32p), _p(dst, _f32p), n, float(thr), ctypes.c_uint64(int(seed)),
+                                 H.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _p(mask, _u8p))
+    if not ok:
+        return None, None
+    return H, mask[:n]

@@ -1,0 +1,120 @@
+"""CPU tests of the host-side mirror of the reference interface: geodetic conversion against golden
+vectors generated from the reference's own geodetic_conv.py, the homography plausibility gate, the
+lazy cv2 stand-ins, parameter handling and the pure-Python parts of the facade."""
+import json
+import math
+import os
+from decimal import Decimal
+
+import numpy as np
+import pytest
+
+from image_matching_amd import cvtypes, params, utils
+from image_matching_amd.geodetic_conv import GeodeticConvert
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_geodetic_matches_reference_golden():
+    cases = json.load(open(os.path.join(GOLD, "geodetic_conv.json")))["cases"]
+    assert len(cases) == 40
+    for c in cases:
+        g = GeodeticConvert()
+        g.initialiseReference(*c["ref"])
+        assert np.allclose(g.geodetic2Ned(*c["geodetic"]), c["ned_out"], rtol=0, atol=1e-6)
+        assert np.allclose(g.geodetic2Ecef(*c["geodetic"]), c["ecef_out"], rtol=0, atol=1e-6)
+        assert np.allclose(g.ned2Geodetic(*c["ned_in"]), c["geodetic_out"], rtol=0, atol=1e-9)
+
+
+def _quad(pts):
+    return np.float32(pts).reshape(-1, 1, 2)
+
+
+def test_isconvex_gate_messages():
+    h, w = 480, 640
+    good = _quad([[0, 0], [0, h - 1], [w - 1, h - 1], [w - 1, 0]])
+    assert utils.isConvex(good, (h, w), 0.35, 0.5, 2.0) == (True, "TRANSFROM IS GOOOOOOOD!")
+    bow = _quad([[0, 0], [0, h], [w, h], [w / 2, h * 0.9]])  # concave
+    ok, msg = utils.isConvex(bow, (h, w), 0.35, 0.5, 2.0)
+    assert not ok and msg == "ANSWER IS NOT CONVEX"
+    small = _quad([[0, 0], [0, 100], [133, 100], [133, 0]])
+    ok, msg = utils.isConvex(small, (h, w), 0.35, 0.5, 2.0)
+    assert not ok and msg.startswith("SHAPE NOT FIT, shape[0]/dist1: 4.8 hs: 2.0")
+    big = _quad([[0, 0], [0, 2000], [2666, 2000], [2666, 0]])
+    ok, msg = utils.isConvex(big, (h, w), 0.35, 0.5, 2.0)
+    assert not ok and msg.startswith("SHAPE NOT FIT, shape[0]/dist1: 0.24 ls: 0.5")
+    wide = _quad([[0, 0], [0, 479], [250, 479], [250, 0]])
+    ok, msg = utils.isConvex(wide, (h, w), 0.35, 0.5, 2.0)
+    assert not ok and msg == "SHAPE NOT FIT, shape[1]/dist2: 2.56 hs: 0.5"  # the reference prints ls here
+    skew = _quad([[0, 0], [300, 479], [939, 479], [639, 0]])
+    ok, msg = utils.isConvex(skew, (h, w), 0.35, 0.5, 2.0)
+    assert not ok and msg.startswith("ANGLE NOT FIT, angle_1 delta: ")
+
+
+def test_line_intersection_and_angle():
+    x, y = utils.line_intersection(((0, 0), (10, 10)), ((0, 10), (10, 0)))
+    assert (x, y) == (5.0, 5.0)
+    with pytest.raises(Exception, match="lines do not intersect"):
+        utils.line_intersection(((0, 0), (1, 1)), ((0, 1), (1, 2)))
+    assert math.isclose(utils.angle((1, 0), (0, 0), (0, 1)), math.pi / 2)
+    assert math.isclose(utils.angle((0, 1), (0, 0), (1, 0)), 3 * math.pi / 2)
+    assert utils.CrossProduct([[0, 0], [1, 0], [0, 1]]) == 1
+    assert utils.calculate_euqlidian_dist((0, 0), (3, 4)) == 5
+
+
+def test_cv_standins():
+    rec = np.array([[1.5, 2.5, 3, 45, 0.1, 513, -1], [7, 8, 2, 90, 0.2, 66049, -1]], np.float32)
+    kps = cvtypes.KeyPoints(rec)
+    assert len(kps) == 2 and kps[1].pt == (7.0, 8.0) and kps[0].octave == 513 and kps[1].class_id == -1
+    assert [k.size for k in kps] == [3.0, 2.0] and kps.xy.shape == (2, 2)
+    m = cvtypes.DMatch(3, 4, 0, 1.25)
+    assert (m.queryIdx, m.trainIdx, m.imgIdx, m.distance) == (3, 4, 0, 1.25)
+
+
+def test_params_table_and_resize_dims():
+    assert params.get_param("points_quality_sift") == 0.7 and params.get_param("image_size_sift") == 640
+    params.set_params(points_quality_sift=0.75)
+    assert params.get_param("points_quality_sift") == 0.75
+    params.set_params(points_quality_sift=0.7)
+    with pytest.raises(KeyError):
+        params.get_param("no_such_key")
+    # dsize arithmetic of utils.resize_img (utils.py:18-19): Decimal truncation
+    assert int(1280 * Decimal(640 / 1280)) == 640 and int(720 * Decimal(640 / 1280)) == 360
+    assert int(1000 * Decimal(0.3)) == 299  # 0.3 as a double is below 0.3
+
+
+def test_perspective_transform_and_angles():
+    from image_matching_amd.match_finder import match_finder, perspective_transform
+    th = 0.3
+    H = np.array([[math.cos(th), -math.sin(th), 5], [math.sin(th), math.cos(th), -7], [0, 0, 1.0]])
+    pts = np.float32([[0, 0], [10, 0], [10, 20]]).reshape(-1, 1, 2)
+    out = perspective_transform(pts, H)
+    assert out.dtype == np.float32 and out.shape == (3, 1, 2)
+    assert np.allclose(out[1, 0], [5 + 10 * math.cos(th), -7 + 10 * math.sin(th)], atol=1e-5)
+    with pytest.raises(ValueError):
+        perspective_transform(pts, None)
+    roll, pitch, yaw = match_finder.get_angles_from_homography(None, H)
+    assert math.isclose(yaw, th, abs_tol=1e-12) and roll == math.atan2(5, 1) and pitch == math.atan2(0, math.cos(th))
+
+
+def test_roi_policy_host_logic():
+    from image_matching_amd.match_finder import match_finder
+
+    class M:
+        pass
+    mp = M()
+    mp.img = np.zeros((1000, 1500), np.uint8)
+    mp.pixel_size = Decimal("0.5")
+    mf = match_finder.__new__(match_finder)
+    borders = match_finder.roi_from_map(mf, mp, 500, 400)
+    # step_y uses cel_x (reference match_finder.py:98): 400 + (1000 - 400*3)/2 = 300
+    assert borders[0] == [0, 550, 0, 330] and all(b[1] <= 1500 and b[3] <= 1000 for b in borders)
+    r = match_finder.create_roi_from_border(mf, mp, [0, 550, 0, 330])
+    assert r.img.shape == (550, 330)  # axes as in the reference (match_finder.py:125)
+    cadr = M()
+    cadr.img = np.zeros((480, 640), np.uint8)
+    cadr.cadr_scale = 0.5
+    r = match_finder.roi_from_last_xy(mf, mp, 300.0, 200.0, cadr, 1.0, 0.0)
+    assert (r.pixel_x_main_map, r.pixel_y_main_map) == (0, 0) and r.img.shape == (1000, 1240)
+    s, bigger = match_finder.find_scale(mf, Decimal("0.5"), Decimal("0.25"))
+    assert bigger is True and s == Decimal("0.5")
