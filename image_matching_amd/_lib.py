@@ -44,6 +44,7 @@ SIGNATURES = {
     "imatch_synchronize": (ctypes.c_int, [c_vp]),
     "imatch_set_profiling": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "imatch_knn2_kernel_ms": (ctypes.c_int, [c_vp, c_f32p]),
+    "imatch_sift_pyramid_ms": (ctypes.c_int, [c_vp, c_f32p]),
     "imatch_features_from_host_f32": (ctypes.c_int, [c_vp, c_f32p, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_features_from_host_u8": (ctypes.c_int, [c_vp, c_u8p, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_features_from_device_u8": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
@@ -56,6 +57,9 @@ SIGNATURES = {
                                           ctypes.c_int, ctypes.c_int]),
     "imatch_sift_extract": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(SiftParams), ctypes.POINTER(c_vp)]),
+    "imatch_sift_extract_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.POINTER(SiftParams), ctypes.POINTER(c_vp)]),
+    "imatch_features_desc_u8_dev": (ctypes.c_int, [c_vp, c_vp]),
     "imatch_features_download": (ctypes.c_int, [c_vp, c_f32p, c_f32p]),
     "imatch_features_image": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int]),
     "imatch_sift_debug_layer": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
@@ -126,6 +130,10 @@ class Features:
                 self._h, _ptr(kp, c_f32p) if keypoints else None, _ptr(desc, c_f32p) if descriptors else None))
         return kp, desc
 
+    def desc_u8_dev(self, out_ptr):
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.imatch_features_desc_u8_dev(self._h, c_vp(out_ptr)))
+
     def image(self, h, w):
         out = np.empty((h, w), np.uint8)
         with self.ctx.lock:
@@ -193,6 +201,12 @@ class Context:
             self._check(self.lib.imatch_knn2_kernel_ms(self._h, ctypes.byref(ms)))
         return ms.value
 
+    def sift_pyramid_ms(self):
+        ms = ctypes.c_float(0)
+        with self.lock:
+            self._check(self.lib.imatch_sift_pyramid_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
     # -- descriptor sets ----------------------------------------------------------------
     def features(self, desc):
         """Upload a [n,128] float32 or uint8 descriptor matrix."""
@@ -258,6 +272,17 @@ class Context:
                                                      img.strides[0], ctypes.byref(params), ctypes.byref(h)))
             n = self.lib.imatch_features_count(h)
         return Features(self, h, n)
+
+    def sift_extract_dev(self, img_ptr, h, w, stride=None, params=None):
+        """SIFT on a u8 image already in device memory (e.g. a torch tensor's data_ptr())."""
+        params = params or SiftParams()
+        hnd = c_vp()
+        with self.lock:
+            self._check(self.lib.imatch_sift_extract_dev(self._h, c_vp(img_ptr), int(h), int(w),
+                                                         int(stride if stride is not None else w),
+                                                         ctypes.byref(params), ctypes.byref(hnd)))
+            n = self.lib.imatch_features_count(hnd)
+        return Features(self, hnd, n)
 
     def sift_debug_layer(self, kind, o, i):
         r, c = ctypes.c_int(), ctypes.c_int()

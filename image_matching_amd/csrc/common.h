@@ -18,7 +18,8 @@ struct imatch_ctx {
     size_t hs_bytes;
     // optional event bracket around the dominant kernel (imatch_set_profiling)
     int prof;
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev0, ev1;   // kNN MFMA kernel
+    hipEvent_t ev2, ev3;   // SIFT scale-space stage (upsample .. last extrema scan)
     // SIFT pyramid arena of the last extraction (kept for reuse by the next frame of the same size)
     struct imatch_sift_state* sift;
 };

@@ -74,6 +74,8 @@ void imatch_destroy(imatch_ctx* ctx) {
     if (ctx->hs) (void)hipHostFree(ctx->hs);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
     (void)hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -88,6 +90,8 @@ int imatch_set_profiling(imatch_ctx* ctx, int on) {
     if (on && !ctx->ev0) {
         HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
         HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
+        HIP_TRY(ctx, hipEventCreate(&ctx->ev2));
+        HIP_TRY(ctx, hipEventCreate(&ctx->ev3));
     }
     ctx->prof = on ? 1 : 0;
     return IMATCH_OK;
@@ -98,6 +102,14 @@ int imatch_knn2_kernel_ms(imatch_ctx* ctx, float* ms) {
     if (!ctx->ev0) return imatch_set_err(ctx, IMATCH_EINVAL, "profiling was never enabled");
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
     HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return IMATCH_OK;
+}
+
+int imatch_sift_pyramid_ms(imatch_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return IMATCH_EINVAL;
+    if (!ctx->ev2) return imatch_set_err(ctx, IMATCH_EINVAL, "profiling was never enabled");
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev3));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev2, ctx->ev3));
     return IMATCH_OK;
 }
 

@@ -159,18 +159,30 @@ __device__ inline void top2_insert(int& s1, int& j1, int& s2, int& j2, int s, in
     }
 }
 
-// merges the partial lists of one query, adds |q|^2, writes (ssd1, idx1, ssd2, idx2)
-__global__ void knn2_finish_kernel(const float2* __restrict__ pb, const int2* __restrict__ pi, int nLists,
-                                   int64_t Qpad, const float* __restrict__ qnorm, int64_t nq, int64_t nt,
-                                   int idx_offset, int4* __restrict__ out) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
+// merges the partial lists of one query, adds |q|^2, writes (ssd1, idx1, ssd2, idx2).
+// 256 threads = 16 queries x 16 list slices; the slices are combined through LDS.
+__global__ void __launch_bounds__(256)
+knn2_finish_kernel(const float2* __restrict__ pb, const int2* __restrict__ pi, int nLists, int64_t Qpad,
+                   const float* __restrict__ qnorm, int64_t nq, int64_t nt, int idx_offset, int4* __restrict__ out) {
+    __shared__ int4 part[16][16];
+    const int ql = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int64_t q = (int64_t)blockIdx.x * 16 + ql;
     int s1 = INT_MAX, s2 = INT_MAX, j1 = INT_MAX, j2 = INT_MAX;
-    for (int l = 0; l < nLists; ++l) {
-        const float2 b = pb[(int64_t)l * Qpad + q];
-        const int2 i = pi[(int64_t)l * Qpad + q];
-        if (i.x >= 0 && i.x < nt) top2_insert(s1, j1, s2, j2, (int)b.x, i.x);
-        if (i.y >= 0 && i.y < nt) top2_insert(s1, j1, s2, j2, (int)b.y, i.y);
+    if (q < nq) {
+        for (int l = slice; l < nLists; l += 16) {
+            const float2 b = pb[(int64_t)l * Qpad + q];
+            const int2 i = pi[(int64_t)l * Qpad + q];
+            if (i.x >= 0 && i.x < nt) top2_insert(s1, j1, s2, j2, (int)b.x, i.x);
+            if (i.y >= 0 && i.y < nt) top2_insert(s1, j1, s2, j2, (int)b.y, i.y);
+        }
+    }
+    part[slice][ql] = make_int4(s1, j1, s2, j2);
+    __syncthreads();
+    if (slice != 0 || q >= nq) return;
+    for (int k = 1; k < 16; ++k) {
+        const int4 e = part[k][ql];
+        if (e.y != INT_MAX) top2_insert(s1, j1, s2, j2, e.x, e.y);
+        if (e.w != INT_MAX) top2_insert(s1, j1, s2, j2, e.z, e.w);
     }
     const int qn = (int)qnorm[q];
     int4 o;
@@ -340,6 +352,14 @@ static void launch_knn(imatch_ctx* ctx, const imatch_features* q, const imatch_f
                        (const uint4*)t->desc, t->norm, nQt, nChunks, nStages, Qpad, pb, pi);
 }
 
+// bf16 rows -> u8 rows (integral sets only): the exchange format of the multi-GPU path
+__global__ void unpack_rows_u8_kernel(const uint16_t* __restrict__ src, int64_t n, uint8_t* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 128) return;
+    const uint32_t u = (uint32_t)src[i] << 16;
+    dst[i] = (uint8_t)__uint_as_float(u);
+}
+
 static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t idx_offset,
                     int32_t* out4_dev) {
     if (!ctx || !q || !t || !out4_dev) return imatch_set_err(ctx, IMATCH_EINVAL, "null argument");
@@ -353,9 +373,9 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     const int64_t Qpad = q->n_pad;  // multiple of 1024, so of every qtile
     const int nQt = (int)((q->n + qtile - 1) / qtile);
     const int nStages = (int)(t->n_pad / TN);
-    // chunks: a multiple of 8 (one group per XCD), enough workgroups for ~4 per CU slot, at least 4 stages each
-    int nChunks = (2048 + nQt - 1) / nQt;
-    if (nChunks > nStages / 4) nChunks = nStages / 4;
+    // chunks: a multiple of 8 (one group per XCD), about 4 workgroups per CU, at least 8 stages each
+    int nChunks = (1024 + nQt - 1) / nQt;
+    if (nChunks > nStages / 8) nChunks = nStages / 8;
     nChunks = (nChunks / 8) * 8;
     if (nChunks < 8) nChunks = 8;
     const int64_t nLists = (int64_t)nChunks * 2;
@@ -371,7 +391,7 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     // rows of query tiles beyond nQt are never written by the main kernel but are >= q->n: not read
-    hipLaunchKernelGGL(knn2_finish_kernel, dim3((unsigned)((q->n + 255) / 256)), dim3(256), 0, ctx->stream, pb, pi,
+    hipLaunchKernelGGL(knn2_finish_kernel, dim3((unsigned)((q->n + 15) / 16)), dim3(256), 0, ctx->stream, pb, pi,
                        (int)nLists, Qpad, q->norm, q->n, t->n, idx_offset, (int4*)out4_dev);
     HIP_TRY(ctx, hipGetLastError());
     return IMATCH_OK;
@@ -399,6 +419,19 @@ int imatch_features_from_device_u8(imatch_ctx* ctx, const uint8_t* desc_dev, int
     rc = features_pack<uint8_t>(ctx, f, desc_dev);
     if (rc) { imatch_features_free(f); return rc; }
     *out = f;
+    return IMATCH_OK;
+}
+
+int imatch_features_desc_u8_dev(const imatch_features* f, uint8_t* out_dev) {
+    if (!f) return IMATCH_EINVAL;
+    imatch_ctx* ctx = f->ctx;
+    if (!out_dev && f->n > 0) return imatch_set_err(ctx, IMATCH_EINVAL, "null output");
+    if (!f->integral) return imatch_set_err(ctx, IMATCH_EINVAL, "descriptor set is not integer valued");
+    if (f->n == 0) return IMATCH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(unpack_rows_u8_kernel, dim3((unsigned)((f->n * 128 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint16_t*)f->desc, f->n, out_dev);
+    HIP_TRY(ctx, hipGetLastError());
     return IMATCH_OK;
 }
 

@@ -66,6 +66,7 @@ void imatch_sift_state_free(imatch_ctx* ctx) {
 }
 
 __device__ __forceinline__ int reflect101(int p, int len) {
+    if ((unsigned)p < (unsigned)len) return p;
     if (len == 1) return 0;
     while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
     return p;
@@ -100,34 +101,56 @@ upsample2_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride
 template <int R>
 struct GK { float k[2 * R + 1]; };
 
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// One 64x64 output tile per workgroup. The input tile with its halo is brought into LDS by
+// asynchronous global->LDS loads (global_load_lds, 4 B per lane: the LDS image is lane-linear, the
+// per-lane SOURCE address carries the reflect-101 border mapping), all of them in flight at once.
+// The tile's x origin is x0-16 and its pitch 96 floats for every radius, so LDS rows are 16-B aligned.
 template <int R>
 __global__ void __launch_bounds__(256)
 blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int rows, int cols, GK<R> gk) {
-    constexpr int N = 2 * R + 1, W2 = 64 + 2 * R, H2 = 64 + 2 * R, PITCH = (W2 + 3) & ~3;
-    __shared__ float in[H2 * PITCH];
-    __shared__ float tmp[H2 * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int N = 2 * R + 1, H2 = 64 + 2 * R, PITCH = 96, XO = 16;
+    constexpr int NPIECE = H2 * PITCH / 64;       // 64-float pieces of the input image (H2 is even)
+    __shared__ float lds[H2 * PITCH + H2 * 64];
+    float* in = lds;
+    float* tmp = lds + H2 * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
-    for (int y = wave; y < H2; y += 4) {
-        const float* s = src + (size_t)reflect101(y0 - R + y, rows) * cols;
-        for (int x = lane; x < W2; x += 64) in[y * PITCH + x] = s[reflect101(x0 - R + x, cols)];
+#pragma unroll
+    for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
+        const int piece = j * 4 + wave;
+        if (piece < NPIECE) {
+            const int f = piece * 64 + lane;
+            const int row = f / PITCH, col = f - row * PITCH;
+            const float* g = src + (size_t)reflect101(y0 - R + row, rows) * cols + reflect101(x0 - XO + col, cols);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(in + piece * 64), 4, 0, 0);
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // row pass: 16 threads per row, 4 consecutive outputs each, taps in ascending order
+    // row pass: 16 threads per row, 4 consecutive outputs each, taps in ascending order.
+    // Reads the 16-B aligned superset [A0, A1) of the needed columns [XO-R+xq, XO+R+xq+4).
     {
+        constexpr int A0 = (XO - R) & ~3, A1 = (XO + R + 4 + 3) & ~3, OFF = XO - R - A0;
         const int xq = (tid & 15) * 4;
         for (int y = tid >> 4; y < H2; y += 16) {
-            float v[N + 3];
+            float v[A1 - A0];
 #pragma unroll
-            for (int i = 0; i < N + 3; ++i) v[i] = in[y * PITCH + xq + i];
+            for (int i = 0; i < (A1 - A0) / 4; ++i) {
+                const float4 q = *(const float4*)&in[y * PITCH + xq + A0 + 4 * i];
+                v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+            }
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
             for (int t = 0; t < N; ++t) {
                 const float k = gk.k[t];
-                a0 = fmaf(k, v[t], a0);
-                a1 = fmaf(k, v[t + 1], a1);
-                a2 = fmaf(k, v[t + 2], a2);
-                a3 = fmaf(k, v[t + 3], a3);
+                a0 = fmaf(k, v[OFF + t], a0);
+                a1 = fmaf(k, v[OFF + t + 1], a1);
+                a2 = fmaf(k, v[OFF + t + 2], a2);
+                a3 = fmaf(k, v[OFF + t + 3], a3);
             }
             *(float4*)&tmp[y * 64 + xq] = make_float4(a0, a1, a2, a3);
         }
@@ -135,9 +158,10 @@ blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __res
     __syncthreads();
     // column pass: lane = column, each wave 16 output rows
     {
+        const int w16 = 16 * (tid >> 6);
         float v[16 + 2 * R];
 #pragma unroll
-        for (int i = 0; i < 16 + 2 * R; ++i) v[i] = tmp[(16 * wave + i) * 64 + lane];
+        for (int i = 0; i < 16 + 2 * R; ++i) v[i] = tmp[(w16 + i) * 64 + lane];
         float acc[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 0.f;
@@ -151,10 +175,10 @@ blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __res
         if (gx < cols) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int gy = y0 + 16 * wave + j;
+                const int gy = y0 + w16 + j;
                 if (gy < rows) {
                     dst[(size_t)gy * cols + gx] = acc[j];
-                    if (dog) dog[(size_t)gy * cols + gx] = acc[j] - in[(16 * wave + j + R) * PITCH + lane + R];
+                    if (dog) dog[(size_t)gy * cols + gx] = acc[j] - in[(w16 + j + R) * PITCH + lane + XO];
                 }
             }
         }
@@ -194,31 +218,58 @@ decimate_kernel(const float* __restrict__ src, int scols, float* __restrict__ ds
 }
 
 // ---- findScaleSpaceExtrema: candidate scan ------------------------------------------------------
+// Tile of 64x16 pixels per workgroup; the (nl+2) DoG layers of the tile with a 1-pixel halo are
+// brought into LDS with asynchronous loads (each DoG pixel is read from HBM once), then every thread
+// tests 4 rows x nl layers.
+#define DT_W 64
+#define DT_H 16
+#define DT_PITCH 68
+#define DT_LAYER ((DT_H + 2) * DT_PITCH)
 __global__ void __launch_bounds__(256)
 detect_kernel(PyrTable T, int o, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count) {
-    const int cols = T.cols[o], rows = T.rows[o];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63) + SIFT_IMG_BORDER;
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6) + SIFT_IMG_BORDER;
-    if (c >= cols - SIFT_IMG_BORDER || r >= rows - SIFT_IMG_BORDER) return;
-    for (int i = 1; i <= T.nl; ++i) {
-        const float* img = T.dog[o][i];
-        const float val = img[(size_t)r * cols + c];
-        if (!(fabsf(val) > thr)) continue;
-        const float* prev = T.dog[o][i - 1];
-        const float* next = T.dog[o][i + 1];
-        bool is_max = val > 0, is_min = val < 0;
-        for (int dr = -1; dr <= 1 && (is_max || is_min); ++dr) {
+    __shared__ float lds[(MAX_LAY - 1) * DT_LAYER + 64];
+    const int cols = T.cols[o], rows = T.rows[o], nlay = T.nl + 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * DT_W + SIFT_IMG_BORDER, y0 = blockIdx.y * DT_H + SIFT_IMG_BORDER;
+    const int npiece = (nlay * DT_LAYER + 63) / 64;
+    for (int piece = wave; piece < npiece; piece += 4) {
+        const int f = min(piece * 64 + lane, nlay * DT_LAYER - 1);
+        const int l = f / DT_LAYER, rem = f - l * DT_LAYER;
+        const int row = rem / DT_PITCH, col = rem - row * DT_PITCH;
+        const int gy = min(max(y0 - 1 + row, 0), rows - 1), gx = min(max(x0 - 1 + col, 0), cols - 1);
+        const float* g = T.dog[o][l] + (size_t)gy * cols + gx;
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds + piece * 64), 4, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int c = x0 + lane;
+    if (c >= cols - SIFT_IMG_BORDER) return;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int ly = 4 * (tid >> 6) + rr;  // tile row
+        const int r = y0 + ly;
+        if (r >= rows - SIFT_IMG_BORDER) break;
+        for (int i = 1; i <= T.nl; ++i) {
+            const float* img = lds + i * DT_LAYER + (ly + 1) * DT_PITCH + lane + 1;
+            const float val = img[0];
+            if (!(fabsf(val) > thr)) continue;
+            const float* prev = img - DT_LAYER;
+            const float* next = img + DT_LAYER;
+            bool is_max = val > 0, is_min = val < 0;
 #pragma unroll
-            for (int dc = -1; dc <= 1; ++dc) {
-                const size_t p = (size_t)(r + dr) * cols + c + dc;
-                const float a = img[p], b = prev[p], d = next[p];
-                is_max = is_max && val >= a && val >= b && val >= d;
-                is_min = is_min && val <= a && val <= b && val <= d;
+            for (int dr = -1; dr <= 1; ++dr) {
+#pragma unroll
+                for (int dc = -1; dc <= 1; ++dc) {
+                    const int p = dr * DT_PITCH + dc;
+                    const float a = img[p], b = prev[p], d = next[p];
+                    is_max = is_max && val >= a && val >= b && val >= d;
+                    is_min = is_min && val <= a && val <= b && val <= d;
+                }
             }
-        }
-        if (is_max || is_min) {
-            const int k = atomicAdd(count, 1);
-            if (k < cap) cand[k] = make_uint2((unsigned)((o << 8) | i), (unsigned)((r << 16) | c));
+            if (is_max || is_min) {
+                const int k = atomicAdd(count, 1);
+                if (k < cap) cand[k] = make_uint2((unsigned)((o << 8) | i), (unsigned)((r << 16) | c));
+            }
         }
     }
 }
@@ -571,8 +622,8 @@ static int read_counter(imatch_ctx* ctx, const int* dev, int* host) {
 
 extern "C" {
 
-int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, const imatch_sift_params* P,
-                        imatch_features** out) {
+static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, int h, int w, int stride,
+                        const imatch_sift_params* P, imatch_features** out) {
     if (!ctx || !img || !P || !out || h <= 0 || w <= 0 || stride < w)
         return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
     if (P->n_octave_layers < 1 || P->n_octave_layers + 3 > MAX_LAY)
@@ -648,8 +699,8 @@ int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int s
         KpRec* d_kp = (KpRec*)(A + o_kp);
 
         // ---- pre-processing + pyramid
-        HIP_TRY(ctx, hipMemcpy2DAsync(d_img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice,
-                                      ctx->stream));
+        HIP_TRY(ctx, hipMemcpy2DAsync(d_img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
+                                      img_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
         const uint8_t* d_src = d_img;
         if (P->clahe) {
             int rc = imatch_clahe_dev(ctx, d_img, h, w, w, P->clahe_clip, P->clahe_tiles_x, P->clahe_tiles_y, d_clahe,
@@ -658,6 +709,7 @@ int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int s
             d_src = d_clahe;
         }
         HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
+        if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
         hipLaunchKernelGGL(upsample2_kernel, dim3((bcols + 63) / 64, (brows + 3) / 4), dim3(256), 0, ctx->stream, d_src, h,
                            w, w, d_up);
         const float sig_diff = sqrtf(fmaxf((float)P->sigma * (float)P->sigma - 0.5f * 0.5f * 4, 0.01f));
@@ -681,10 +733,11 @@ int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int s
                 if (rc) return rc;
             }
             if (rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER)
-                hipLaunchKernelGGL(detect_kernel, dim3((cols - 2 * SIFT_IMG_BORDER + 63) / 64, (rows - 2 * SIFT_IMG_BORDER + 3) / 4),
+                hipLaunchKernelGGL(detect_kernel, dim3((cols - 2 * SIFT_IMG_BORDER + DT_W - 1) / DT_W, (rows - 2 * SIFT_IMG_BORDER + DT_H - 1) / DT_H),
                                    dim3(256), 0, ctx->stream, T, o, thr, d_cand, cap, d_cnt);
         }
         HIP_TRY(ctx, hipGetLastError());
+        if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
         int n_cand = 0;
         rc = read_counter(ctx, d_cnt, &n_cand);
         if (rc) return rc;
@@ -768,6 +821,16 @@ int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int s
         return IMATCH_OK;
     }
     return imatch_set_err(ctx, IMATCH_ESIZE, "keypoint lists kept overflowing");
+}
+
+int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, const imatch_sift_params* P,
+                        imatch_features** out) {
+    return sift_extract(ctx, img, 0, h, w, stride, P, out);
+}
+
+int imatch_sift_extract_dev(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int stride,
+                            const imatch_sift_params* P, imatch_features** out) {
+    return sift_extract(ctx, img_dev, 1, h, w, stride, P, out);
 }
 
 int imatch_features_download(const imatch_features* f, float* kp, float* desc) {

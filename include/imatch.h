@@ -50,6 +50,9 @@ int imatch_synchronize(imatch_ctx* ctx);
  * imatch_knn2_kernel_ms waits for the last launch and returns its duration. */
 int imatch_set_profiling(imatch_ctx* ctx, int on);
 int imatch_knn2_kernel_ms(imatch_ctx* ctx, float* ms);
+/* Same bracket around the scale-space stage of the last imatch_sift_extract (upsample, the Gaussian
+ * / DoG kernels, decimation and the extrema scans): the stage SURVEY 8(d)'s 475.7 B/pixel covers. */
+int imatch_sift_pyramid_ms(imatch_ctx* ctx, float* ms);
 
 /* Descriptor sets resident in HBM ----------------------------------------- */
 /* Replaces cv2.cuda_GpuMat(descriptors) (MF:187-188), but the set outlives the call:
@@ -58,6 +61,9 @@ int imatch_features_from_host_f32(imatch_ctx* ctx, const float* desc, int64_t n,
 int imatch_features_from_host_u8(imatch_ctx* ctx, const uint8_t* desc, int64_t n, int d, imatch_features** out);
 /* Same, from a u8 [n][128] matrix already in device memory (a torch tensor's data_ptr). */
 int imatch_features_from_device_u8(imatch_ctx* ctx, const uint8_t* desc_dev, int64_t n, int d, imatch_features** out);
+/* Writes the set as u8 [n][128] into device memory (asynchronously, on the context's stream): the
+ * exchange format of the multi-GPU path (queries are all-gathered as bytes). Integral sets only. */
+int imatch_features_desc_u8_dev(const imatch_features* f, uint8_t* out_dev);
 int64_t imatch_features_count(const imatch_features* f);
 /* 1 when every descriptor value of the set is an integer in 0..255 (kNN is then bit-exact), else 0. */
 int imatch_features_is_integral(const imatch_features* f);
@@ -90,6 +96,10 @@ typedef struct imatch_sift_params {
  * imatch_knn2) that also carries the keypoints and, with clahe=1, the equalised image. */
 int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride,
                         const imatch_sift_params* params, imatch_features** out);
+/* Same, for an image already in device memory (the frame hand-off from a torch tensor / a capture
+ * pipeline that decodes on the GPU; the reference has no device images). */
+int imatch_sift_extract_dev(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int stride,
+                            const imatch_sift_params* params, imatch_features** out);
 /* kp: [K][7] = x, y, size, angle, response, octave, class_id (cv2.KeyPoint fields, OpenCV's final
  * order: sorted and de-duplicated as KeyPointsFilter::removeDuplicatedSorted leaves them);
  * desc: [K][128] f32, integer valued 0..255. Either pointer may be null. */
