@@ -1,0 +1,103 @@
+"""CPU: the CLAHE / INTER_AREA / SIFT / homography oracle against its committed golden vectors and
+against properties that do not need cv2 (known blob position and scale, descriptor normalisation,
+rotation covariance, planted homography through the whole oracle chain)."""
+import os
+
+import numpy as np
+from scipy import ndimage
+
+import oracle
+from image_matching_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_golden_vectors():
+    g = np.load(os.path.join(GOLD, "sift_small.npz"))
+    for name in ("tex", "odd", "blob"):
+        img = g[name + "_img"]
+        assert np.array_equal(oracle.clahe(img), g[name + "_clahe"])
+        r = oracle.sift(g[name + "_clahe"])
+        assert np.array_equal(r.kp, g[name + "_kp"]) and np.array_equal(r.desc.astype(np.uint8), g[name + "_desc"])
+        dw, dh = int(img.shape[1] * 0.61), int(img.shape[0] * 0.61)
+        assert np.array_equal(oracle.resize_area(img, (dw, dh)), g[name + "_area"])
+    H, mask = oracle.homography(g["h_src"], g["h_dst"], 0.1, seed=11)
+    assert np.allclose(H, g["h_H"], rtol=0, atol=1e-12) and np.array_equal(mask, g["h_mask"])
+
+
+def test_gaussian_kernel_and_blur():
+    for sigma, n in [(1.2489996, 11), (1.2262735, 11), (1.5450078, 13), (1.9465878, 17), (2.4525470, 21), (3.0900156, 27)]:
+        k = oracle.gauss_kernel(sigma)
+        assert len(k) == n and abs(k.sum() - 1) < 1e-6 and np.array_equal(k, k[::-1]) and k.argmax() == n // 2
+    rng = np.random.default_rng(0)
+    a = (rng.random((50, 70)) * 255).astype(np.float32)
+    k = oracle.gauss_kernel(1.6).astype(np.float64)
+    ref = ndimage.correlate1d(ndimage.correlate1d(a.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    assert np.abs(oracle.gauss_blur(a, 1.6) - ref).max() < 1e-3
+
+
+def test_blob_position_scale_and_descriptor_invariants():
+    yy, xx = np.mgrid[0:128, 0:160]
+    sig = 4.0
+    img = 60 + 150 * np.exp(-((xx - 70.25) ** 2 + (yy - 60.5) ** 2) / (2 * sig * sig))
+    r = oracle.sift(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+    assert len(r.kp) >= 1
+    k = r.kp[np.argmax(r.kp[:, 4])]
+    assert abs(k[0] - 70.25) < 0.5 and abs(k[1] - 60.5) < 0.5
+    # a Gaussian blob of std s is a DoG extremum near sigma = s*sqrt(2)... size = 2*sigma; allow the layer quantisation
+    assert 1.6 * sig < k[2] < 3.6 * sig
+    oct_lo = int(k[5]) & 255
+    assert (oct_lo if oct_lo < 128 else oct_lo - 256) >= -1 and 1 <= ((int(k[5]) >> 8) & 255) <= 3
+    d = r.desc
+    assert np.array_equal(d, np.rint(d)) and d.min() >= 0 and d.max() <= 255
+    assert np.all(np.abs(np.linalg.norm(d, axis=1) - 512) < 12)
+
+
+def test_keypoint_order_and_rotation_covariance():
+    m = synth.synth_map(512, seed=8)
+    img = oracle.clahe(m[100:292, 100:356])
+    r = oracle.sift(img)
+    kp = r.kp
+    assert len(kp) > 50
+    assert np.array_equal(np.lexsort((kp[:, 3], -kp[:, 2], kp[:, 1], kp[:, 0])), np.arange(len(kp)))
+    rot = np.ascontiguousarray(np.rot90(img))          # 90 degrees counter-clockwise
+    r2 = oracle.sift(rot)
+    # (x, y) in img -> (y, W-1-x) in rot90(img); angles shift by +90 (image y axis points down)
+    want = np.c_[kp[:, 1], img.shape[1] - 1 - kp[:, 0]]
+    from scipy.spatial import cKDTree
+    dist, j = cKDTree(r2.kp[:, :2]).query(want)
+    close = dist < 0.75
+    assert close.mean() > 0.85
+    # matching keypoints have (nearly) the same descriptor: rotation invariance of the 4x4x8 histogram
+    l2 = np.linalg.norm(r.desc[close] - r2.desc[j[close]], axis=1)
+    assert np.median(l2) < 60
+
+
+def test_clahe_and_resize_properties():
+    m = synth.synth_map(256, seed=2)
+    c = oracle.clahe(m)
+    assert c.shape == m.shape and c.std() > m.std()                     # equalisation spreads the histogram
+    assert np.array_equal(oracle.clahe(np.full((64, 80), 9, np.uint8)), oracle.clahe(np.full((64, 80), 9, np.uint8)))
+    half = oracle.resize_area(m, (128, 128))
+    box = (m[0::2, 0::2].astype(int) + m[1::2, 0::2] + m[0::2, 1::2] + m[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(half, box)
+    third = oracle.resize_area(m[:255, :255], (85, 85))
+    box3 = m[:255, :255].reshape(85, 3, 85, 3).astype(np.float32).sum((1, 3)) * np.float32(1 / 9)
+    assert np.abs(third.astype(int) - np.rint(box3).astype(int)).max() <= 1
+    frac = oracle.resize_area(m, (100, 77))
+    assert frac.shape == (77, 100) and abs(float(frac.mean()) - float(m.mean())) < 1.0
+
+
+def test_whole_chain_recovers_planted_homography():
+    m = synth.synth_map(768, seed=5)
+    frame, H = synth.synth_frame(m, 1, size=(240, 320), scale_range=(0.9, 1.1))
+    a = oracle.sift(oracle.clahe(frame))
+    b = oracle.sift(oracle.clahe(m))
+    idx, dist = oracle.knn2(a.desc, b.desc, threads=8)
+    gq, gt, _ = oracle.ratio(idx, dist, 0.7)
+    assert len(gq) > 10
+    He, _ = oracle.homography(a.kp[gq, :2], b.kp[gt, :2], 0.1, seed=0)
+    c = np.array([[0, 0, 1], [0, 239, 1], [319, 239, 1], [319, 0, 1.0]])
+    pa, pb = c @ He.T, c @ H.T
+    # a few dozen inliers on a 320x240 frame: statistical error of the estimate, not a parity bar
+    assert np.abs(pa[:, :2] / pa[:, 2:] - pb[:, :2] / pb[:, 2:]).max() < 3.0
