@@ -30,6 +30,7 @@ struct imatch_features {
     int64_t n_pad;    // rows allocated, multiple of IMATCH_ROW_PAD; pad rows are zero with norm +inf
     uint16_t* desc;   // bf16 [n_pad][128], device
     float* norm;      // f32 [n_pad] squared L2 norms (exact integers for integral sets), device
+    float* hneg;      // f32 [n_pad] = -norm/2 (pad rows: -inf): the MFMA accumulator's start value; norm + n_pad
     int* flag;        // device int: 1 if some value was not an integer in 0..255
     int integral;     // host copy of !flag, valid after creation
     // sets produced by imatch_sift_extract also carry:

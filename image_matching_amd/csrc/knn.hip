@@ -22,22 +22,89 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-#define TN 64                        // train rows per LDS stage
-#define STAGE_U4 (TN * 16 + TN / 4)  // uint4 per stage: TN rows x 256 B, then TN f32 norms
-
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
-template <int NW, int QB>
-__global__ void __launch_bounds__(NW * 64, 2)
-knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ tnorm,
-            int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi) {
-    __shared__ uint4 lds[2 * STAGE_U4];
+// Asynchronous global -> LDS copy (LDS-DMA), written as inline asm so that the compiler does not
+// track it: hipcc otherwise drains vmcnt(0) before every LDS access that follows a global_load_lds,
+// which serialises the prefetch with the compute it is meant to overlap. Completion is handled by the
+// explicit s_waitcnt vmcnt(0) + barrier at the top of every stage. base: wave-uniform global pointer;
+// voff: per-lane byte offset; lds_addr: wave-uniform LDS byte address (lane i lands at lds_addr + i*size).
+__device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* base, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void glds4_sc1(const void* base, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+// lane id recomputed on the spot (volatile: not CSE'd into a long-lived register that would be spilled;
+// spill reloads are vector-memory operations and would drain the LDS-DMA queue)
+__device__ __forceinline__ unsigned lane_now() {
+    unsigned l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const unsigned long long b = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(LDS_AS const char*)p);
+}
+
+// float <-> int with the same ordering (negative floats included), for atomicMin on thresholds
+__device__ __forceinline__ int ord_i(float f) { const int i = __float_as_int(f); return i ^ ((i >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float ord_f(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
+
+__device__ __forceinline__ float max16(const f32x16& a) {
+    const float m0 = fmaxf(fmaxf(a[0], a[1]), a[2]), m1 = fmaxf(fmaxf(a[3], a[4]), a[5]);
+    const float m2 = fmaxf(fmaxf(a[6], a[7]), a[8]), m3 = fmaxf(fmaxf(a[9], a[10]), a[11]);
+    const float m4 = fmaxf(fmaxf(a[12], a[13]), a[14]);
+    return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), a[15]));
+}
+
+// QB 32-query blocks per wave (4 waves: 128*QB queries per workgroup), TN train rows per LDS stage.
+//
+// Per 32x32 block the accumulator starts at C = -|t|^2/2 (per result row), so the MFMA chain ends
+// with acc = q.t - |t|^2/2 = -v/2 where v = |t|^2 - 2 q.t (exact: every partial sum is a multiple of
+// 1/2 below 2^23). A result can enter the query's top-2 only if v <= T, T = an upper bound of the
+// query's final second-best, i.e. acc >= G = -T/2: the hot epilogue is a 16-way max (v_max3 tree) and
+// ONE compare per block; the insertion path is wave-uniform and rare, and works on LDS (the block's
+// accumulators are parked in a scratch slot, the query's running top-2 lives in LDS), so the hot loop
+// carries only G in registers. T is shared chip-wide: every wave publishes its second-best with
+// atomicMin into gthr[query] once per stage and fetches the minimum back (asynchronously, into LDS),
+// so short train chunks do not keep loose thresholds. The chain of block u+1 is issued before the
+// epilogue of block u (two accumulator sets), so the VALU work hides under the MFMAs.
+// The whole kernel stays below 256 VGPRs: the MFMAs then keep their accumulators in VGPRs, which the
+// VALU reads directly, and two workgroups share a CU.
+template <int QB, int TN>
+__global__ void __launch_bounds__(256, 2)
+knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ thneg,
+            int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi,
+            int* __restrict__ gthr) {
+    constexpr int STAGE_U4 = TN * 16 + TN / 4;   // uint4 per stage: TN rows x 256 B, then TN f32 (-|t|^2/2)
+    constexpr int NT = TN / 32;                  // 32-row tiles per stage
+    constexpr int ST_F = QB * 256;               // floats of top-2 state per wave: [QB][b1,b2,i1,i2][64]
+    constexpr int TH_F = QB * 64;                // floats of fetched thresholds per wave: [QB][64]
+    __shared__ uint4 lds[2 * STAGE_U4 + (4 * ST_F + 4 * 1024 + 4 * TH_F) / 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
+    float* const extra = (float*)(lds + 2 * STAGE_U4);
+    float* const st = extra + wave * ST_F;
+    float* const scratch = extra + 4 * ST_F + wave * 1024;
+    float* const thl = extra + 4 * ST_F + 4 * 1024 + wave * TH_F;
 
-    // blocks b and b+8 share an XCD (its L2): give them the same train chunk, different query tiles
+    // workgroups b and b+8 share an XCD (its L2): same train chunk, different query tiles
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int chunk = (j / nQt) * 8 + xcd;
     const int qt = j % nQt;
@@ -46,7 +113,7 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
     const int s_end = (int)((int64_t)nStages * (chunk + 1) / nChunks);
 
     // resident query fragments: lane holds q[row r][k = 16 ks + 8 h .. +7] = 16-byte chunk 2 ks + h
-    const int64_t qrow0 = (int64_t)qt * (NW * 32 * QB) + wave * (32 * QB);
+    const int64_t qrow0 = (int64_t)qt * (4 * 32 * QB) + wave * (32 * QB);
     bf16x8 qf[QB][8];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
@@ -56,30 +123,32 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
             qf[qb][ks] = __builtin_bit_cast(bf16x8, u);
         }
 
-    float b1[QB], b2[QB];
-    int i1[QB], i2[QB];
+    const int* gq = gthr + qrow0;                 // wave-uniform base of this wave's thresholds
+    float G[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        b1[qb] = FLT_MAX; b2[qb] = FLT_MAX; i1[qb] = -1; i2[qb] = -1;
+        st[qb * 256 + lane] = FLT_MAX; st[qb * 256 + 64 + lane] = FLT_MAX;
+        st[qb * 256 + 128 + lane] = __int_as_float(-1); st[qb * 256 + 192 + lane] = __int_as_float(-1);
+        const int t0 = __hip_atomic_load(gq + qb * 32 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        thl[qb * 64 + lane] = __int_as_float(t0);
+        G[qb] = -0.5f * ord_f(t0);
     }
 
-    // stage loader: slot = 16-byte piece of the stage image; LDS is lane-linear, the swizzle
-    // chunk' = chunk ^ (row & 15) is applied to the per-lane source address
+    // Stage loader. The LDS image is lane-linear; the swizzle chunk' = chunk ^ (row & 15) is applied to
+    // the per-lane SOURCE address. slot = i*256 + wave*64 + lane -> row = i*16 + (wave*4 + lane/16), so
+    // every piece is (uniform base) + (one per-lane byte offset that never changes).
+    const unsigned lds0 = lds_addr_of(lds);
     auto stage = [&](int s, int buf) {
-        const uint4* src = Td + (int64_t)s * TN * 16;
+        const unsigned ln = lane_now();
+        const unsigned r0 = (unsigned)wave * 4u + (ln >> 4);
+        const unsigned lane_off = (r0 * 16 + ((ln & 15) ^ (r0 & 15))) * 16;   // bytes
+        const char* src = (const char*)(Td + (int64_t)s * TN * 16);
 #pragma unroll
-        for (int i = 0; i < (TN * 16) / (NW * 64); ++i) {
-            const int slot = i * NW * 64 + wave * 64 + lane;
-            const int row = slot >> 4, cp = slot & 15;
-            const uint4* g = src + row * 16 + (cp ^ (row & 15));
-            uint4* l = lds + buf * STAGE_U4 + i * NW * 64 + wave * 64;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)l, 16, 0, 0);
-        }
-        if (wave == 0) {
-            const float* g = tnorm + (int64_t)s * TN + lane;
-            uint4* l = lds + buf * STAGE_U4 + TN * 16;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)l, 4, 0, 0);
-        }
+        for (int i = 0; i < (TN * 16) / 256; ++i)
+            glds16(uniform_ptr(src + i * 4096), lane_off, lds0 + (buf * STAGE_U4 + i * 256 + wave * 64) * 16);
+        if (wave < TN / 64)
+            glds4(uniform_ptr(thneg + (int64_t)s * TN + wave * 64), ln * 4,
+                  lds0 + (buf * STAGE_U4 + TN * 16) * 16 + wave * 256);
     };
 
     if (s_begin < s_end) stage(s_begin, 0);
@@ -87,55 +156,114 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
         const int buf = (s - s_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // Thresholds fetched during the previous exchange -> G; publish this wave's second-best only when
+        // it lowers the chip-wide value. Exchanges happen at every stage while a chunk is young (that
+        // is when bounds move), then at every fourth stage.
+        const int age = s - s_begin;
+        const bool exchange = age < 8 || (age & 3) == 0;
+        if (exchange) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float tg = ord_f(__float_as_int(thl[qb * 64 + lane]));
+                G[qb] = fmaxf(G[qb], -0.5f * tg);
+                const float b2 = st[qb * 256 + 64 + lane];
+                if (b2 < tg) atomicMin(const_cast<int*>(gq) + qb * 32 + r, ord_i(b2));
+            }
+        }
+        // asynchronous loads: next stage, and the chip-wide thresholds for the next exchange (sc1: from memory)
         if (s + 1 < s_end) stage(s + 1, buf ^ 1);
+        if (exchange) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                glds4_sc1(uniform_ptr(gq + qb * 32), (lane_now() & 31) * 4, lds_addr_of(thl) + qb * 256);
+        }
+        const unsigned lf = lane_now();
+        const unsigned frag_off = (lf & 31) * 256u + ((((lf >> 5) ^ lf) & 15) << 4);
 
         const uint4* img = lds + buf * STAGE_U4;
-#pragma unroll
-        for (int tile = 0; tile < TN / 32; ++tile) {
-            bf16x8 af[8];
+        bf16x8 af[8];
+        f32x16 hneg;
+        // chunk (2ks+h)^(r&15) = ((h^r)&15) ^ 2ks and the row's byte offset has its low 8 bits clear, so
+        // all eight fragment addresses of a tile are ONE per-lane address XOR an immediate
+        auto load_tile = [&](int tile) {
+            const unsigned a0 = (unsigned)tile * 8192u + frag_off;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                uint4 u = img[(tile * 32 + r) * 16 + ((2 * ks + h) ^ (r & 15))];
+                uint4 u = *(const uint4*)((const char*)img + (a0 ^ (unsigned)(ks << 5)));
                 af[ks] = __builtin_bit_cast(bf16x8, u);
             }
-            // norms of the 16 train rows this lane sees: row(reg) = (reg&3) + 8*(reg>>2) + 4*h
-            float tnr[16];
+            // -|t|^2/2 of the 16 train rows this lane sees: row(reg) = (reg&3) + 8*(reg>>2) + 4*h
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint4 u = img[TN * 16 + tile * 8 + 2 * g + h];
-                tnr[4 * g + 0] = __uint_as_float(u.x);
-                tnr[4 * g + 1] = __uint_as_float(u.y);
-                tnr[4 * g + 2] = __uint_as_float(u.z);
-                tnr[4 * g + 3] = __uint_as_float(u.w);
+                hneg[4 * g + 0] = __uint_as_float(u.x);
+                hneg[4 * g + 1] = __uint_as_float(u.y);
+                hneg[4 * g + 2] = __uint_as_float(u.z);
+                hneg[4 * g + 3] = __uint_as_float(u.w);
             }
-            const int rowbase = s * TN + tile * 32 + 4 * h;
+        };
+        auto chain = [&](int qb) {
+            f32x16 acc = hneg;
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                f32x16 acc = {0};
+            for (int ks = 0; ks < 8; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], qf[qb][ks], acc, 0, 0, 0);
+            return acc;
+        };
+        // Insertion path (rare, wave-uniform entry). Rows are visited in ascending train index with
+        // strict <: OpenCV's lowest-index tie-break.
+        auto epilogue = [&](const f32x16& a, int qb, int tile) {
+            if (__builtin_amdgcn_ballot_w64(max16(a) >= G[qb])) {
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], qf[qb][ks], acc, 0, 0, 0);
-                float v[16];
-                const float thr = b2[qb];
-                bool hit = false;
-#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) scratch[reg * 64 + lane] = a[reg];
+                float* sq = st + qb * 256;
+                float b1 = sq[lane], b2 = sq[64 + lane];
+                int i1 = __float_as_int(sq[128 + lane]), i2 = __float_as_int(sq[192 + lane]);
+                const int rowbase = s * TN + tile * 32 + 4 * h;
+                const float g = G[qb];
+#pragma unroll 1
                 for (int reg = 0; reg < 16; ++reg) {
-                    v[reg] = fmaf(acc[reg], -2.0f, tnr[reg]);
-                    hit |= v[reg] < thr;
-                }
-                if (__builtin_amdgcn_ballot_w64(hit)) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        if (__builtin_amdgcn_ballot_w64(v[reg] < b2[qb])) {
-                            const int idx = rowbase + (reg & 3) + 8 * (reg >> 2);
-                            const float x = v[reg];
-                            if (x < b1[qb]) {
-                                b2[qb] = b1[qb]; i2[qb] = i1[qb]; b1[qb] = x; i1[qb] = idx;
-                            } else if (x < b2[qb]) {
-                                b2[qb] = x; i2[qb] = idx;
-                            }
+                    const float v = scratch[reg * 64 + lane];
+                    if (v >= g) {
+                        const float x = -2.0f * v;
+                        const int idx = rowbase + (reg & 3) + 8 * (reg >> 2);
+                        if (x < b1) {
+                            b2 = b1; i2 = i1; b1 = x; i1 = idx;
+                        } else if (x < b2) {
+                            b2 = x; i2 = idx;
                         }
                     }
+                }
+                sq[lane] = b1; sq[64 + lane] = b2;
+                sq[128 + lane] = __int_as_float(i1); sq[192 + lane] = __int_as_float(i2);
+                G[qb] = fmaxf(g, -0.5f * b2);
+            }
+        };
+
+        load_tile(0);
+        f32x16 acc0 = chain(0), acc1;
+        if constexpr (QB == 1) {
+            // one block per tile: no chain to hide the epilogue under
+#pragma unroll 1
+            for (int tile = 0; tile < NT; ++tile) {
+                const f32x16 a = acc0;
+                if (tile + 1 < NT) {
+                    load_tile(tile + 1);
+                    acc0 = chain(0);
+                }
+                epilogue(a, 0, tile);
+            }
+        } else {
+#pragma unroll 1
+            for (int tile = 0; tile < NT; ++tile) {
+#pragma unroll
+                for (int qb = 0; qb < QB; qb += 2) {
+                    // block qb+1 of this tile is issued, then block qb is examined
+                    acc1 = chain(qb + 1);
+                    if (qb == QB - 2 && tile + 1 < NT) load_tile(tile + 1);  // the tile's last chain is out
+                    epilogue(acc0, qb, tile);
+                    if (qb + 2 < QB) acc0 = chain(qb + 2);
+                    else if (tile + 1 < NT) acc0 = chain(0);                  // first block of the next tile
+                    epilogue(acc1, qb + 1, tile);
                 }
             }
         }
@@ -146,8 +274,8 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int64_t o = list * Qpad + qrow0 + qb * 32 + r;
-        pb[o] = make_float2(b1[qb], b2[qb]);
-        pi[o] = make_int2(i1[qb], i2[qb]);
+        pb[o] = make_float2(st[qb * 256 + lane], st[qb * 256 + 64 + lane]);
+        pi[o] = make_int2(__float_as_int(st[qb * 256 + 128 + lane]), __float_as_int(st[qb * 256 + 192 + lane]));
     }
 }
 
@@ -260,7 +388,7 @@ ratio_kernel(const int4* __restrict__ in, int64_t nq, double ratio, int* __restr
 // one wave per row; lane handles 2 values
 template <typename T>
 __global__ void pack_rows_kernel(const T* __restrict__ src, int64_t n, int64_t n_pad, uint16_t* __restrict__ dst,
-                                 float* __restrict__ norm, int* __restrict__ flag) {
+                                 float* __restrict__ norm, float* __restrict__ hneg, int* __restrict__ flag) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n_pad) return;
@@ -278,7 +406,10 @@ __global__ void pack_rows_kernel(const T* __restrict__ src, int64_t n, int64_t n
     float s = ra * ra + rb * rb;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) norm[row] = (row < n) ? s : INFINITY;
+    if (lane == 0) {
+        norm[row] = (row < n) ? s : INFINITY;
+        hneg[row] = (row < n) ? -0.5f * s : -INFINITY;
+    }
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(flag, 1);
 }
 
@@ -290,13 +421,14 @@ int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out) {
     f->n_pad = ((n + IMATCH_ROW_PAD - 1) / IMATCH_ROW_PAD) * IMATCH_ROW_PAD;
     if (f->n_pad == 0) f->n_pad = IMATCH_ROW_PAD;
     if (hipMalloc((void**)&f->desc, (size_t)f->n_pad * 256) != hipSuccess ||
-        hipMalloc((void**)&f->norm, (size_t)f->n_pad * 4) != hipSuccess ||
+        hipMalloc((void**)&f->norm, (size_t)f->n_pad * 8) != hipSuccess ||
         hipMalloc((void**)&f->flag, 256) != hipSuccess) {
         if (f->desc) (void)hipFree(f->desc);
         if (f->norm) (void)hipFree(f->norm);
         free(f);
         return imatch_set_err(ctx, IMATCH_ENOMEM, "device alloc for %lld descriptors", (long long)n);
     }
+    f->hneg = f->norm + f->n_pad;
     *out = f;
     return IMATCH_OK;
 }
@@ -307,7 +439,7 @@ static int features_pack(imatch_ctx* ctx, imatch_features* f, const T* src_dev) 
     const int rows_per_block = 4;
     const unsigned grid = (unsigned)((f->n_pad + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(pack_rows_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, src_dev, f->n, f->n_pad, f->desc,
-                       f->norm, f->flag);
+                       f->norm, f->hneg, f->flag);
     HIP_TRY(ctx, hipGetLastError());
     int flag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&flag, f->flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -343,21 +475,22 @@ static int features_from_host(imatch_ctx* ctx, const T* desc, int64_t n, int d, 
     return IMATCH_OK;
 }
 
-// ---- launch -------------------------------------------------------------------------------
-template <int NW, int QB>
-static void launch_knn(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int nQt, int nChunks,
-                       int nStages, int64_t Qpad, float2* pb, int2* pi) {
-    const unsigned grid = (unsigned)(nQt * nChunks);
-    hipLaunchKernelGGL((knn2_kernel<NW, QB>), dim3(grid), dim3(NW * 64), 0, ctx->stream, (const uint4*)q->desc,
-                       (const uint4*)t->desc, t->norm, nQt, nChunks, nStages, Qpad, pb, pi);
-}
-
 // bf16 rows -> u8 rows (integral sets only): the exchange format of the multi-GPU path
 __global__ void unpack_rows_u8_kernel(const uint16_t* __restrict__ src, int64_t n, uint8_t* __restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * 128) return;
     const uint32_t u = (uint32_t)src[i] << 16;
     dst[i] = (uint8_t)__uint_as_float(u);
+}
+
+// ---- launch -------------------------------------------------------------------------------
+template <int QB, int TN>
+static void launch_knn(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int nQt, int nChunks,
+                       int64_t Qpad, float2* pb, int2* pi, int* gthr) {
+    const unsigned grid = (unsigned)(nQt * nChunks);
+    const int nStages = (int)(t->n_pad / TN);
+    hipLaunchKernelGGL((knn2_kernel<QB, TN>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)q->desc,
+                       (const uint4*)t->desc, t->hneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr);
 }
 
 static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t idx_offset,
@@ -368,29 +501,33 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     // query tile per workgroup: 4 waves x 32*QB queries
     int QB = 4;
     if (q->n <= 128) QB = 1;
-    else if (q->n <= 1024) QB = 2;
+    else if (q->n <= 512) QB = 2;
+    const int TNs = 64;
     const int qtile = 4 * 32 * QB;
     const int64_t Qpad = q->n_pad;  // multiple of 1024, so of every qtile
     const int nQt = (int)((q->n + qtile - 1) / qtile);
-    const int nStages = (int)(t->n_pad / TN);
-    // chunks: a multiple of 8 (one group per XCD), about 4 workgroups per CU, at least 8 stages each
-    int nChunks = (1024 + nQt - 1) / nQt;
-    if (nChunks > nStages / 8) nChunks = nStages / 8;
+    const int nStages = (int)(t->n_pad / TNs);
+    // chunks: a multiple of 8 (one group per XCD); about two workgroups per CU slot; >= 4 stages per chunk
+    const int slots = 512;
+    int nChunks = (2 * slots + nQt - 1) / nQt;
+    if (nChunks > nStages / 4) nChunks = nStages / 4;
     nChunks = (nChunks / 8) * 8;
     if (nChunks < 8) nChunks = 8;
     const int64_t nLists = (int64_t)nChunks * 2;
     const size_t pbytes = (size_t)nLists * Qpad * 8;
-    int rc = imatch_ws_reserve(ctx, 2 * pbytes);
+    const size_t gbytes = ((size_t)Qpad * 4 + 255) & ~(size_t)255;
+    int rc = imatch_ws_reserve(ctx, 2 * pbytes + gbytes);
     if (rc) return rc;
     float2* pb = (float2*)ctx->ws;
     int2* pi = (int2*)((char*)ctx->ws + pbytes);
+    int* gthr = (int*)((char*)ctx->ws + 2 * pbytes);
+    HIP_TRY(ctx, hipMemsetAsync(gthr, 0x7f, gbytes, ctx->stream));  // 0x7f7f7f7f = 3.39e38 as a float
     if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (QB == 4) launch_knn<4, 4>(ctx, q, t, nQt, nChunks, nStages, Qpad, pb, pi);
-    else if (QB == 2) launch_knn<4, 2>(ctx, q, t, nQt, nChunks, nStages, Qpad, pb, pi);
-    else launch_knn<4, 1>(ctx, q, t, nQt, nChunks, nStages, Qpad, pb, pi);
+    if (QB == 4) launch_knn<4, 64>(ctx, q, t, nQt, nChunks, Qpad, pb, pi, gthr);
+    else if (QB == 2) launch_knn<2, 64>(ctx, q, t, nQt, nChunks, Qpad, pb, pi, gthr);
+    else launch_knn<1, 64>(ctx, q, t, nQt, nChunks, Qpad, pb, pi, gthr);
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    // rows of query tiles beyond nQt are never written by the main kernel but are >= q->n: not read
     hipLaunchKernelGGL(knn2_finish_kernel, dim3((unsigned)((q->n + 15) / 16)), dim3(256), 0, ctx->stream, pb, pi,
                        (int)nLists, Qpad, q->norm, q->n, t->n, idx_offset, (int4*)out4_dev);
     HIP_TRY(ctx, hipGetLastError());
