@@ -104,81 +104,120 @@ struct GK { float k[2 * R + 1]; };
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
-// One 64x64 output tile per workgroup. The input tile with its halo is brought into LDS by
-// asynchronous global->LDS loads (global_load_lds, 4 B per lane: the LDS image is lane-linear, the
-// per-lane SOURCE address carries the reflect-101 border mapping), all of them in flight at once.
-// The tile's x origin is x0-16 and its pitch 96 floats for every radius, so LDS rows are 16-B aligned.
+// One 64x32 output tile per workgroup (4 workgroups share a CU, so one tile's loads overlap the
+// others' arithmetic). Tile fill goes through registers: 16-byte global loads of rows y and y+1 (all
+// of a thread's loads are issued before its first LDS write), written to LDS as interleaved row
+// pairs -- element (y, x) at ((y/2)*P + x)*2 + (y&1) -- so that one 16-byte LDS read yields
+// (y,x) (y+1,x) (y,x+1) (y+1,x+1) and the row pass works on two rows per instruction (v_pk_fma_f32).
+// The column pass packs two adjacent columns per thread the same way. Each output is still one
+// ascending-tap fma chain: bit-identical to the scalar form the CPU oracle computes.
+// (Measured alternatives, tools/blur_bench.hip: 4-byte LDS-DMA fill is instruction-rate bound at
+// ~1.6 TB/s; a lane-per-row/lane-per-column variant with padded pitches was slower for R <= 10.)
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int R>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int rows, int cols, GK<R> gk) {
-    constexpr int N = 2 * R + 1, H2 = 64 + 2 * R, PITCH = 96, XO = 16;
-    constexpr int NPIECE = H2 * PITCH / 64;       // 64-float pieces of the input image (H2 is even)
-    __shared__ float lds[H2 * PITCH + H2 * 64];
+    constexpr int N = 2 * R + 1, TH = 32, H2 = TH + 2 * R;      // H2 is even
+    constexpr int XO = (R + 3) & ~3, P = 64 + 2 * XO;            // x origin of the tile = x0 - XO; P % 8 == 0
+    constexpr int NX4 = P / 4, NITEM = (H2 / 2) * NX4;           // one item = 4 columns of a row pair
+    __shared__ float lds[H2 * P + H2 * 64];
     float* in = lds;
-    float* tmp = lds + H2 * PITCH;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    float* tmp = lds + H2 * P;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TH;
+    // Tiles that touch the image border, or images whose rows are not 16-byte multiples, are filled
+    // element-wise with the reflect-101 mapping.
+    const bool interior = (cols & 3) == 0 && x0 - XO >= 0 && x0 - XO + P <= cols && y0 - R >= 0 && y0 - R + H2 <= rows;
+    if (interior) {
+        constexpr int NIT = (NITEM + 255) / 256;
+        float4 a[NIT], b[NIT];
 #pragma unroll
-    for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
-        const int piece = j * 4 + wave;
-        if (piece < NPIECE) {
-            const int f = piece * 64 + lane;
-            const int row = f / PITCH, col = f - row * PITCH;
-            const float* g = src + (size_t)reflect101(y0 - R + row, rows) * cols + reflect101(x0 - XO + col, cols);
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(in + piece * 64), 4, 0, 0);
+        for (int it = 0; it < NIT; ++it) {
+            const int item = min(tid + it * 256, NITEM - 1);
+            const int yp = item / NX4, x4 = item - yp * NX4;
+            const float* g = src + (size_t)(y0 - R + 2 * yp) * cols + (x0 - XO + 4 * x4);
+            a[it] = *(const float4*)g;
+            b[it] = *(const float4*)(g + cols);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = tid + it * 256;
+            if (item < NITEM) {
+                const int yp = item / NX4, x4 = item - yp * NX4;
+                float4* l = (float4*)&in[(yp * P + 4 * x4) * 2];
+                l[0] = make_float4(a[it].x, b[it].x, a[it].y, b[it].y);
+                l[1] = make_float4(a[it].z, b[it].z, a[it].w, b[it].w);
+            }
+        }
+    } else {
+        for (int f = tid; f < H2 * P; f += 256) {
+            const int yp = f / (2 * P), rem = f - yp * (2 * P);
+            const int col = rem >> 1, row = 2 * yp + (rem & 1);
+            in[f] = src[(size_t)reflect101(y0 - R + row, rows) * cols + reflect101(x0 - XO + col, cols)];
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // row pass: 16 threads per row, 4 consecutive outputs each, taps in ascending order.
-    // Reads the 16-B aligned superset [A0, A1) of the needed columns [XO-R+xq, XO+R+xq+4).
+    // row pass: one item = a row pair x 4 consecutive outputs; taps in ascending order
     {
-        constexpr int A0 = (XO - R) & ~3, A1 = (XO + R + 4 + 3) & ~3, OFF = XO - R - A0;
-        const int xq = (tid & 15) * 4;
-        for (int y = tid >> 4; y < H2; y += 16) {
-            float v[A1 - A0];
+        constexpr int E0 = (XO - R) & ~1, E1 = (XO + R + 4 + 1) & ~1, OFF = XO - R - E0;
+        for (int item = tid; item < (H2 / 2) * 16; item += 256) {
+            const int yp = item >> 4, xq = (item & 15) * 4;
+            f2 v[E1 - E0];
 #pragma unroll
-            for (int i = 0; i < (A1 - A0) / 4; ++i) {
-                const float4 q = *(const float4*)&in[y * PITCH + xq + A0 + 4 * i];
-                v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+            for (int i = 0; i < (E1 - E0) / 2; ++i) {
+                const float4 q = *(const float4*)&in[(yp * P + xq + E0 + 2 * i) * 2];
+                v[2 * i] = f2{q.x, q.y};
+                v[2 * i + 1] = f2{q.z, q.w};
             }
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            f2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
 #pragma unroll
             for (int t = 0; t < N; ++t) {
-                const float k = gk.k[t];
-                a0 = fmaf(k, v[OFF + t], a0);
-                a1 = fmaf(k, v[OFF + t + 1], a1);
-                a2 = fmaf(k, v[OFF + t + 2], a2);
-                a3 = fmaf(k, v[OFF + t + 3], a3);
+                const f2 k = {gk.k[t], gk.k[t]};
+                a0 = __builtin_elementwise_fma(k, v[OFF + t], a0);
+                a1 = __builtin_elementwise_fma(k, v[OFF + t + 1], a1);
+                a2 = __builtin_elementwise_fma(k, v[OFF + t + 2], a2);
+                a3 = __builtin_elementwise_fma(k, v[OFF + t + 3], a3);
             }
-            *(float4*)&tmp[y * 64 + xq] = make_float4(a0, a1, a2, a3);
+            *(float4*)&tmp[(2 * yp) * 64 + xq] = make_float4(a0.x, a1.x, a2.x, a3.x);
+            *(float4*)&tmp[(2 * yp + 1) * 64 + xq] = make_float4(a0.y, a1.y, a2.y, a3.y);
         }
     }
     __syncthreads();
-    // column pass: lane = column, each wave 16 output rows
+    // column pass: thread = 2 adjacent columns x 4 output rows
     {
-        const int w16 = 16 * (tid >> 6);
-        float v[16 + 2 * R];
+        const int cp = tid & 31, r4 = (tid >> 5) * 4;
+        f2 v[4 + 2 * R];
 #pragma unroll
-        for (int i = 0; i < 16 + 2 * R; ++i) v[i] = tmp[(w16 + i) * 64 + lane];
-        float acc[16];
+        for (int i = 0; i < 4 + 2 * R; ++i) v[i] = *(const f2*)&tmp[(r4 + i) * 64 + 2 * cp];
+        f2 acc[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[j] = f2{0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < N; ++t) {
-            const float k = gk.k[t];
+            const f2 k = {gk.k[t], gk.k[t]};
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = fmaf(k, v[t + j], acc[j]);
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_elementwise_fma(k, v[t + j], acc[j]);
         }
-        const int gx = x0 + lane;
-        if (gx < cols) {
+        const int gx = x0 + 2 * cp;
+        const bool pair_ok = ((cols & 1) == 0) && gx + 1 < cols;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int gy = y0 + w16 + j;
-                if (gy < rows) {
-                    dst[(size_t)gy * cols + gx] = acc[j];
-                    if (dog) dog[(size_t)gy * cols + gx] = acc[j] - in[(w16 + j + R) * PITCH + lane + XO];
+        for (int j = 0; j < 4; ++j) {
+            const int gy = y0 + r4 + j;
+            if (gy >= rows || gx >= cols) continue;
+            const int yy = r4 + j + R;
+            const float c0 = in[((yy >> 1) * P + 2 * cp + XO) * 2 + (yy & 1)];
+            const float c1 = in[((yy >> 1) * P + 2 * cp + 1 + XO) * 2 + (yy & 1)];
+            const size_t o = (size_t)gy * cols + gx;
+            if (pair_ok) {
+                *(f2*)&dst[o] = acc[j];
+                if (dog) *(f2*)&dog[o] = f2{acc[j].x - c0, acc[j].y - c1};
+            } else {
+                dst[o] = acc[j].x;
+                if (dog) dog[o] = acc[j].x - c0;
+                if (gx + 1 < cols) {
+                    dst[o + 1] = acc[j].y;
+                    if (dog) dog[o + 1] = acc[j].y - c1;
                 }
             }
         }
@@ -217,6 +256,55 @@ decimate_kernel(const float* __restrict__ src, int scols, float* __restrict__ ds
     dst[(size_t)y * cols + x] = src[(size_t)(2 * y) * scols + 2 * x];
 }
 
+// ---- appending records to a global list ---------------------------------------------------------
+// One atomicAdd on the list's single counter per candidate caps a kernel at ~100 appends/us for the
+// whole chip (every op serialises in one L2 channel), which was 3.5 ms of the octave-0 scan. Waves
+// therefore stage their records in LDS (slots from ballot prefix counts, no LDS atomics) and a
+// workgroup reserves its range with ONE atomicAdd when it is done; a wave whose stage fills flushes
+// on its own. The list order was never defined (the host sorts), so nothing downstream changes.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename Rec, int STAGE>
+__device__ __forceinline__ void stage_append(Rec* stage, int& n_staged, bool hit, const Rec& rec, Rec* out, int cap,
+                                             int* count) {
+    const unsigned long long mk = __ballot(hit);
+    if (mk == 0) return;  // wave-uniform
+    const int lane = threadIdx.x & 63, np = __popcll(mk);
+    if (n_staged + np > STAGE) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(count, n_staged);
+        base = __shfl(base, 0);
+        wave_lds_fence();
+        for (int j = lane; j < n_staged; j += 64)
+            if (base + j < cap) out[base + j] = stage[j];
+        wave_lds_fence();
+        n_staged = 0;
+    }
+    if (hit) stage[n_staged + __popcll(mk & ((1ull << lane) - 1ull))] = rec;
+    n_staged += np;
+}
+
+// Every wave of the (4-wave) workgroup must call this, in converged control flow. wcnt: __shared__ int[5].
+template <typename Rec>
+__device__ __forceinline__ void stage_flush_block(const Rec* stage, int n_staged, int* wcnt, Rec* out, int cap,
+                                                  int* count) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wcnt[wv] = n_staged;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        wcnt[4] = t ? atomicAdd(count, t) : 0;
+    }
+    __syncthreads();
+    int base = wcnt[4];
+    for (int w = 0; w < wv; ++w) base += wcnt[w];
+    for (int j = lane; j < n_staged; j += 64)
+        if (base + j < cap) out[base + j] = stage[j];
+}
+
 // ---- findScaleSpaceExtrema: candidate scan ------------------------------------------------------
 // Tile of 64x16 pixels per workgroup; the (nl+2) DoG layers of the tile with a 1-pixel halo are
 // brought into LDS with asynchronous loads (each DoG pixel is read from HBM once), then every thread
@@ -225,9 +313,12 @@ decimate_kernel(const float* __restrict__ src, int scols, float* __restrict__ ds
 #define DT_H 16
 #define DT_PITCH 68
 #define DT_LAYER ((DT_H + 2) * DT_PITCH)
+#define DET_STAGE 128  // candidates a wave stages in LDS before it has to flush on its own
 __global__ void __launch_bounds__(256)
-detect_kernel(PyrTable T, int o, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count) {
+detect_kernel_generic(PyrTable T, int o, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count) {
     __shared__ float lds[(MAX_LAY - 1) * DT_LAYER + 64];
+    __shared__ uint2 stage_all[4][DET_STAGE];
+    __shared__ int wcnt[5];
     const int cols = T.cols[o], rows = T.rows[o], nlay = T.nl + 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,34 +335,104 @@ detect_kernel(PyrTable T, int o, float thr, uint2* __restrict__ cand, int cap, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int c = x0 + lane;
-    if (c >= cols - SIFT_IMG_BORDER) return;
+    const bool col_ok = c < cols - SIFT_IMG_BORDER;
+    int n_staged = 0;
+    uint2* stage = stage_all[tid >> 6];
     for (int rr = 0; rr < 4; ++rr) {
         const int ly = 4 * (tid >> 6) + rr;  // tile row
         const int r = y0 + ly;
-        if (r >= rows - SIFT_IMG_BORDER) break;
+        if (r >= rows - SIFT_IMG_BORDER) break;  // wave-uniform
         for (int i = 1; i <= T.nl; ++i) {
             const float* img = lds + i * DT_LAYER + (ly + 1) * DT_PITCH + lane + 1;
             const float val = img[0];
-            if (!(fabsf(val) > thr)) continue;
-            const float* prev = img - DT_LAYER;
-            const float* next = img + DT_LAYER;
-            bool is_max = val > 0, is_min = val < 0;
+            bool is_max = false, is_min = false;
+            if (col_ok && fabsf(val) > thr) {
+                const float* prev = img - DT_LAYER;
+                const float* next = img + DT_LAYER;
+                is_max = val > 0; is_min = val < 0;
 #pragma unroll
-            for (int dr = -1; dr <= 1; ++dr) {
+                for (int dr = -1; dr <= 1; ++dr) {
 #pragma unroll
-                for (int dc = -1; dc <= 1; ++dc) {
-                    const int p = dr * DT_PITCH + dc;
-                    const float a = img[p], b = prev[p], d = next[p];
-                    is_max = is_max && val >= a && val >= b && val >= d;
-                    is_min = is_min && val <= a && val <= b && val <= d;
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        const int p = dr * DT_PITCH + dc;
+                        const float a = img[p], b = prev[p], d = next[p];
+                        is_max = is_max && val >= a && val >= b && val >= d;
+                        is_min = is_min && val <= a && val <= b && val <= d;
+                    }
                 }
             }
-            if (is_max || is_min) {
-                const int k = atomicAdd(count, 1);
-                if (k < cap) cand[k] = make_uint2((unsigned)((o << 8) | i), (unsigned)((r << 16) | c));
+            stage_append<uint2, DET_STAGE>(stage, n_staged, is_max || is_min,
+                                           make_uint2((unsigned)((o << 8) | i), (unsigned)((r << 16) | c)), cand, cap, count);
+        }
+    }
+    stage_flush_block(stage, n_staged, wcnt, cand, cap, count);
+}
+
+// nOctaveLayers = 3 (5 DoG layers), the default: a streaming scan with no LDS and no barrier. A wave
+// owns a strip of 62 output columns (lanes 0 and 63 carry the halo columns) and walks 32 output rows;
+// per row and layer it loads ONE value per lane (a coalesced 256-byte row segment), gets the left and
+// right neighbours from the adjacent lanes, and keeps a 3-row window of horizontal max/min in
+// registers. Instead of 26 compares per pixel and layer, every layer's 3x3 max and min are built
+// separably and shared by the three layers that need them: val is a maximum iff
+// val >= max(M[i-1], M[i], M[i+1]), with M the 3x3 max that includes val itself.
+#define DS_COLS 62
+#define DS_ROWS 32
+__global__ void __launch_bounds__(256)
+detect_stream_kernel(PyrTable T, int o, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count) {
+    const int cols = T.cols[o], rows = T.rows[o];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = SIFT_IMG_BORDER + blockIdx.x * DS_COLS + lane - 1;
+    const int ry0 = SIFT_IMG_BORDER + (blockIdx.y * 4 + wv) * DS_ROWS;
+    __shared__ uint2 stage_all[4][DET_STAGE];
+    __shared__ int wcnt[5];
+    uint2* stage = stage_all[wv];
+    int n_staged = 0;
+    const bool wave_active = ry0 < rows - SIFT_IMG_BORDER;  // wave-uniform
+    const int xc = min(max(x, 0), cols - 1);
+    const float* p[5];
+#pragma unroll
+    for (int l = 0; l < 5; ++l) p[l] = T.dog[o][l] + xc;
+    const bool col_ok = lane >= 1 && lane <= DS_COLS && x < cols - SIFT_IMG_BORDER;
+    float hm[5][3], hn[5][3], cv[3][3];
+    auto load_row = [&](int row, int slot) {
+        const size_t off = (size_t)min(row, rows - 1) * cols;
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            const float v = p[l][off];
+            const float a = __shfl_up(v, 1), d = __shfl_down(v, 1);
+            hm[l][slot] = fmaxf(fmaxf(a, v), d);
+            hn[l][slot] = fminf(fminf(a, v), d);
+            if (l >= 1 && l <= 3) cv[l - 1][slot] = v;
+        }
+    };
+    if (wave_active) {
+        load_row(ry0 - 1, 0);
+        load_row(ry0, 1);
+    }
+    for (int k = 0; wave_active && k < DS_ROWS; k += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int r = ry0 + k + u;            // output row: rows r-1, r, r+1 sit in the three slots
+            load_row(r + 1, (u + 2) % 3);
+            float M[5], m[5];
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                M[l] = fmaxf(fmaxf(hm[l][0], hm[l][1]), hm[l][2]);
+                m[l] = fminf(fminf(hn[l][0], hn[l][1]), hn[l][2]);
+            }
+            const bool row_ok = col_ok && k + u < DS_ROWS && r < rows - SIFT_IMG_BORDER;
+#pragma unroll
+            for (int i = 1; i <= 3; ++i) {
+                const float val = cv[i - 1][(u + 1) % 3];
+                const bool is_max = val > thr && val >= fmaxf(fmaxf(M[i - 1], M[i]), M[i + 1]);
+                const bool is_min = val < -thr && val <= fminf(fminf(m[i - 1], m[i]), m[i + 1]);
+                stage_append<uint2, DET_STAGE>(stage, n_staged, row_ok && (is_max || is_min),
+                                               make_uint2((unsigned)((o << 8) | i), (unsigned)((r << 16) | x)), cand, cap,
+                                               count);
             }
         }
     }
+    stage_flush_block(stage, n_staged, wcnt, cand, cap, count);
 }
 
 // ---- adjustLocalExtrema ---------------------------------------------------------------------------
@@ -364,78 +525,89 @@ __device__ __forceinline__ float atan2_deg(float y, float x) {
 }
 
 // ---- calcOrientationHist + peak picking: one wavefront per refined keypoint ---------------------
+// A wave walks `kpw` consecutive keypoints (1 for a frame, so the launch stays wide; up to 8 for a
+// map) and stages its output records, so the output counter sees one atomicAdd per workgroup.
+#define ORI_STAGE 64
 __global__ void __launch_bounds__(256)
-orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, int n_ref, KpRec* __restrict__ out, int cap,
+orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, int n_ref, int kpw, KpRec* __restrict__ out, int cap,
               int* __restrict__ count) {
     __shared__ unsigned long long hacc[4][SIFT_ORI_HIST_BINS];
     __shared__ float hsm[4][SIFT_ORI_HIST_BINS + 4];
+    __shared__ KpRec stage_all[4][ORI_STAGE];
+    __shared__ int wcnt[5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int id = blockIdx.x * 4 + wave;
-    const bool active = id < n_ref;
     const int n = SIFT_ORI_HIST_BINS;
-    if (lane < n) hacc[wave][lane] = 0ull;
-    __syncthreads();
-    RefinedKp k;
-    if (active) {
-        k = ref[id];
-        const int rows = T.rows[k.o], cols = T.cols[k.o];
-        const float* img = T.gauss[k.o][k.layer];
-        const float scl_octv = k.size * 0.5f / (1 << k.o);
-        const int radius = __float2int_rn(4.5f * scl_octv);
-        const float sigma = 1.5f * scl_octv;
-        const float expf_scale = -1.f / (2.f * sigma * sigma);
-        const int side = 2 * radius + 1;
-        for (int p = lane; p < side * side; p += 64) {
-            const int i = p / side - radius, j = p % side - radius;
-            const int y = k.r + i, x = k.c + j;
-            if (y <= 0 || y >= rows - 1 || x <= 0 || x >= cols - 1) continue;
-            const float dx = img[(size_t)y * cols + x + 1] - img[(size_t)y * cols + x - 1];
-            const float dy = img[(size_t)(y - 1) * cols + x] - img[(size_t)(y + 1) * cols + x];
-            const float w = expf((i * i + j * j) * expf_scale);
-            const float ori = atan2_deg(dy, dx);
-            const float mag = sqrtf(dx * dx + dy * dy);
-            int bin = __float2int_rn((n / 360.f) * ori);
-            if (bin >= n) bin -= n;
-            if (bin < 0) bin += n;
-            atomicAdd(&hacc[wave][bin], (unsigned long long)(long long)__float2int_rn(w * mag * FIX_SCALE));
+    KpRec* stage = stage_all[wave];
+    int n_staged = 0;
+    for (int t = 0; t < kpw; ++t) {
+        const int id = (blockIdx.x * 4 + wave) * kpw + t;
+        const bool active = id < n_ref;
+        if (lane < n) hacc[wave][lane] = 0ull;
+        __syncthreads();
+        RefinedKp k;
+        if (active) {
+            k = ref[id];
+            const int rows = T.rows[k.o], cols = T.cols[k.o];
+            const float* img = T.gauss[k.o][k.layer];
+            const float scl_octv = k.size * 0.5f / (1 << k.o);
+            const int radius = __float2int_rn(4.5f * scl_octv);
+            const float sigma = 1.5f * scl_octv;
+            const float expf_scale = -1.f / (2.f * sigma * sigma);
+            const int side = 2 * radius + 1;
+            for (int p = lane; p < side * side; p += 64) {
+                const int i = p / side - radius, j = p % side - radius;
+                const int y = k.r + i, x = k.c + j;
+                if (y <= 0 || y >= rows - 1 || x <= 0 || x >= cols - 1) continue;
+                const float dx = img[(size_t)y * cols + x + 1] - img[(size_t)y * cols + x - 1];
+                const float dy = img[(size_t)(y - 1) * cols + x] - img[(size_t)(y + 1) * cols + x];
+                const float w = expf((i * i + j * j) * expf_scale);
+                const float ori = atan2_deg(dy, dx);
+                const float mag = sqrtf(dx * dx + dy * dy);
+                int bin = __float2int_rn((n / 360.f) * ori);
+                if (bin >= n) bin -= n;
+                if (bin < 0) bin += n;
+                atomicAdd(&hacc[wave][bin], (unsigned long long)(long long)__float2int_rn(w * mag * FIX_SCALE));
+            }
         }
-    }
-    __syncthreads();
-    if (lane < n) hsm[wave][lane + 2] = (float)(long long)hacc[wave][lane] * FIX_INV;
-    __syncthreads();
-    if (lane == 0) {
-        float* th = &hsm[wave][2];
-        th[-1] = th[n - 1]; th[-2] = th[n - 2]; th[n] = th[0]; th[n + 1] = th[1];
-    }
-    __syncthreads();
-    float hv = 0.f;
-    if (lane < n) {
-        const float* th = &hsm[wave][2];
-        hv = (th[lane - 2] + th[lane + 2]) * (1.f / 16.f) + (th[lane - 1] + th[lane + 1]) * (4.f / 16.f) +
-             th[lane] * (6.f / 16.f);
-    }
-    float mx = lane < n ? hv : -FLT_MAX;
+        __syncthreads();
+        if (lane < n) hsm[wave][lane + 2] = (float)(long long)hacc[wave][lane] * FIX_INV;
+        __syncthreads();
+        if (lane == 0) {
+            float* th = &hsm[wave][2];
+            th[-1] = th[n - 1]; th[-2] = th[n - 2]; th[n] = th[0]; th[n + 1] = th[1];
+        }
+        __syncthreads();
+        float hv = 0.f;
+        if (lane < n) {
+            const float* th = &hsm[wave][2];
+            hv = (th[lane - 2] + th[lane + 2]) * (1.f / 16.f) + (th[lane - 1] + th[lane + 1]) * (4.f / 16.f) +
+                 th[lane] * (6.f / 16.f);
+        }
+        float mx = lane < n ? hv : -FLT_MAX;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    __syncthreads();
-    if (lane < n) hsm[wave][lane] = hv;  // smoothed histogram, plain indexing from here
-    __syncthreads();
-    if (!active || lane >= n) return;
-    const float mag_thr = (float)(mx * 0.8f);
-    const int j = lane, l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
-    const float hl = hsm[wave][l], hj = hsm[wave][j], hr = hsm[wave][r2];
-    if (hj > hl && hj > hr && hj >= mag_thr) {
-        float bin = j + 0.5f * (hl - hr) / (hl - 2 * hj + hr);
-        bin = bin < 0 ? n + bin : bin >= n ? bin - n : bin;
-        float angle = 360.f - (float)((360.f / n) * bin);
-        if (fabsf(angle - 360.f) < FLT_EPSILON) angle = 0.f;
-        const int slot = atomicAdd(count, 1);
-        if (slot < cap) {
-            KpRec o;
-            o.x = k.x; o.y = k.y; o.size = k.size; o.angle = angle; o.response = k.response; o.octave = k.octave;
-            out[slot] = o;
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        __syncthreads();
+        if (lane < n) hsm[wave][lane] = hv;  // smoothed histogram, plain indexing from here
+        __syncthreads();
+        bool peak = false;
+        KpRec o;
+        if (active && lane < n) {
+            const float mag_thr = (float)(mx * 0.8f);
+            const int j = lane, l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
+            const float hl = hsm[wave][l], hj = hsm[wave][j], hr = hsm[wave][r2];
+            if (hj > hl && hj > hr && hj >= mag_thr) {
+                float bin = j + 0.5f * (hl - hr) / (hl - 2 * hj + hr);
+                bin = bin < 0 ? n + bin : bin >= n ? bin - n : bin;
+                float angle = 360.f - (float)((360.f / n) * bin);
+                if (fabsf(angle - 360.f) < FLT_EPSILON) angle = 0.f;
+                o.x = k.x; o.y = k.y; o.size = k.size; o.angle = angle; o.response = k.response; o.octave = k.octave;
+                peak = true;
+            }
         }
+        stage_append<KpRec, ORI_STAGE>(stage, n_staged, peak, o, out, cap, count);
+        __syncthreads();  // hsm/hacc are rewritten by the next keypoint
     }
+    stage_flush_block(stage, n_staged, wcnt, out, cap, count);
 }
 
 // ---- calcSIFTDescriptor: one wavefront per (sorted) keypoint -------------------------------------
@@ -570,7 +742,7 @@ template <int R>
 static void launch_blur_fixed(imatch_ctx* ctx, const float* src, float* dst, float* dog, int rows, int cols, const float* k) {
     GK<R> gk;
     memcpy(gk.k, k, sizeof(gk.k));
-    hipLaunchKernelGGL(blur_kernel<R>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, ctx->stream, src, dst, dog,
+    hipLaunchKernelGGL(blur_kernel<R>, dim3((cols + 63) / 64, (rows + 31) / 32), dim3(256), 0, ctx->stream, src, dst, dog,
                        rows, cols, gk);
 }
 
@@ -732,9 +904,15 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                 rc = gaussian_blur(ctx, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i]);
                 if (rc) return rc;
             }
-            if (rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER)
-                hipLaunchKernelGGL(detect_kernel, dim3((cols - 2 * SIFT_IMG_BORDER + DT_W - 1) / DT_W, (rows - 2 * SIFT_IMG_BORDER + DT_H - 1) / DT_H),
-                                   dim3(256), 0, ctx->stream, T, o, thr, d_cand, cap, d_cnt);
+            if (rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER) {
+                const int iw = cols - 2 * SIFT_IMG_BORDER, ih = rows - 2 * SIFT_IMG_BORDER;
+                if (nl == 3)
+                    hipLaunchKernelGGL(detect_stream_kernel, dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * DS_ROWS - 1) / (4 * DS_ROWS)),
+                                       dim3(256), 0, ctx->stream, T, o, thr, d_cand, cap, d_cnt);
+                else
+                    hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H), dim3(256),
+                                       0, ctx->stream, T, o, thr, d_cand, cap, d_cnt);
+            }
         }
         HIP_TRY(ctx, hipGetLastError());
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
@@ -755,8 +933,9 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             if (rc) return rc;
         }
         if (n_ref > 0) {
-            hipLaunchKernelGGL(orient_kernel, dim3((n_ref + 3) / 4), dim3(256), 0, ctx->stream, T, (const RefinedKp*)d_ref,
-                               n_ref, d_kp, 2 * cap, d_cnt + 2);
+            const int kpw = std::min(8, std::max(1, n_ref / 8192));  // keypoints per wave: >= 2048 workgroups first
+            hipLaunchKernelGGL(orient_kernel, dim3((n_ref + 4 * kpw - 1) / (4 * kpw)), dim3(256), 0, ctx->stream, T,
+                               (const RefinedKp*)d_ref, n_ref, kpw, d_kp, 2 * cap, d_cnt + 2);
             HIP_TRY(ctx, hipGetLastError());
             rc = read_counter(ctx, d_cnt + 2, &n_kp);
             if (rc) return rc;
