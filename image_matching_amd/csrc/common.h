@@ -22,6 +22,15 @@ struct imatch_ctx {
     hipEvent_t ev2, ev3;   // SIFT scale-space stage (upsample .. last extrema scan)
     // SIFT pyramid arena of the last extraction (kept for reuse by the next frame of the same size)
     struct imatch_sift_state* sift;
+    // device blocks handed out by imatch_pool_alloc; freed blocks are kept for the next call
+    struct imatch_pool_block* pool;
+    int pool_n, pool_cap;
+};
+
+struct imatch_pool_block {
+    void* ptr;
+    size_t bytes;
+    int in_use;
 };
 
 struct imatch_features {
@@ -46,6 +55,12 @@ int imatch_features_pack_u8_dev(imatch_ctx* ctx, imatch_features* f, const uint8
 void imatch_sift_state_free(imatch_ctx* ctx);
 int imatch_set_err(imatch_ctx* ctx, int code, const char* fmt, ...);
 int imatch_ws_reserve(imatch_ctx* ctx, size_t bytes);
+// Per-context device block pool: a frame's descriptor set, image copy and result lists come from here,
+// so the per-frame path calls neither hipMalloc nor hipFree (hipFree drains the device). Blocks are
+// only ever used on ctx->stream, so a freed block may be handed out again without a synchronisation.
+void* imatch_pool_alloc(imatch_ctx* ctx, size_t bytes);
+void imatch_pool_free(imatch_ctx* ctx, void* p);
+void imatch_pool_destroy(imatch_ctx* ctx);
 int imatch_hs_reserve(imatch_ctx* ctx, size_t bytes);
 
 #define HIP_TRY(ctx, call)                                                              \

@@ -40,6 +40,76 @@ int imatch_hs_reserve(imatch_ctx* ctx, size_t bytes) {
     return IMATCH_OK;
 }
 
+// ---- device block pool -------------------------------------------------------------------------
+static const size_t POOL_KEEP_BYTES = (size_t)2 << 30;  // free blocks kept at most, in total
+
+void* imatch_pool_alloc(imatch_ctx* ctx, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    int best = -1;
+    for (int i = 0; i < ctx->pool_n; ++i) {
+        const imatch_pool_block& b = ctx->pool[i];
+        if (!b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes + 65536 && (best < 0 || b.bytes < ctx->pool[best].bytes))
+            best = i;
+    }
+    if (best >= 0) {
+        ctx->pool[best].in_use = 1;
+        return ctx->pool[best].ptr;
+    }
+    if (ctx->pool_n == ctx->pool_cap) {
+        const int cap = ctx->pool_cap ? 2 * ctx->pool_cap : 32;
+        imatch_pool_block* nb = (imatch_pool_block*)realloc(ctx->pool, sizeof(imatch_pool_block) * cap);
+        if (!nb) return nullptr;
+        ctx->pool = nb;
+        ctx->pool_cap = cap;
+    }
+    // round up so that frames with slightly different keypoint counts share blocks
+    size_t want = bytes < 65536 ? 65536 : bytes + bytes / 8;
+    want = (want + 65535) & ~(size_t)65535;
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        // give the cached free blocks back and try once more
+        (void)hipStreamSynchronize(ctx->stream);
+        int j = 0;
+        for (int i = 0; i < ctx->pool_n; ++i) {
+            if (ctx->pool[i].in_use) ctx->pool[j++] = ctx->pool[i];
+            else (void)hipFree(ctx->pool[i].ptr);
+        }
+        ctx->pool_n = j;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    ctx->pool[ctx->pool_n++] = imatch_pool_block{p, want, 1};
+    return p;
+}
+
+void imatch_pool_free(imatch_ctx* ctx, void* p) {
+    if (!p) return;
+    size_t free_bytes = 0;
+    int at = -1;
+    for (int i = 0; i < ctx->pool_n; ++i) {
+        if (ctx->pool[i].ptr == p) at = i;
+        else if (!ctx->pool[i].in_use) free_bytes += ctx->pool[i].bytes;
+    }
+    if (at < 0) return;  // not ours
+    if (free_bytes + ctx->pool[at].bytes > POOL_KEEP_BYTES) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(p);
+        ctx->pool[at] = ctx->pool[--ctx->pool_n];
+    } else {
+        ctx->pool[at].in_use = 0;
+    }
+}
+
+void imatch_pool_destroy(imatch_ctx* ctx) {
+    for (int i = 0; i < ctx->pool_n; ++i) (void)hipFree(ctx->pool[i].ptr);
+    free(ctx->pool);
+    ctx->pool = nullptr;
+    ctx->pool_n = ctx->pool_cap = 0;
+}
+
 extern "C" {
 
 int imatch_device_count(void) {
@@ -70,6 +140,7 @@ void imatch_destroy(imatch_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     imatch_sift_state_free(ctx);
+    imatch_pool_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->hs) (void)hipHostFree(ctx->hs);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

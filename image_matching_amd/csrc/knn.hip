@@ -420,14 +420,14 @@ int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out) {
     f->n = n;
     f->n_pad = ((n + IMATCH_ROW_PAD - 1) / IMATCH_ROW_PAD) * IMATCH_ROW_PAD;
     if (f->n_pad == 0) f->n_pad = IMATCH_ROW_PAD;
-    if (hipMalloc((void**)&f->desc, (size_t)f->n_pad * 256) != hipSuccess ||
-        hipMalloc((void**)&f->norm, (size_t)f->n_pad * 8) != hipSuccess ||
-        hipMalloc((void**)&f->flag, 256) != hipSuccess) {
-        if (f->desc) (void)hipFree(f->desc);
-        if (f->norm) (void)hipFree(f->norm);
+    // one block: bf16 rows, then norm + hneg (f32 each), then the integrality flag
+    f->desc = (uint16_t*)imatch_pool_alloc(ctx, (size_t)f->n_pad * (256 + 8) + 256);
+    if (!f->desc) {
         free(f);
         return imatch_set_err(ctx, IMATCH_ENOMEM, "device alloc for %lld descriptors", (long long)n);
     }
+    f->norm = (float*)((char*)f->desc + (size_t)f->n_pad * 256);
+    f->flag = (int*)((char*)f->desc + (size_t)f->n_pad * (256 + 8));
     f->hneg = f->norm + f->n_pad;
     *out = f;
     return IMATCH_OK;
@@ -448,8 +448,15 @@ static int features_pack(imatch_ctx* ctx, imatch_features* f, const T* src_dev) 
     return IMATCH_OK;
 }
 
+// u8 rows are integral by type: no flag to read back, so this only queues work on the stream
 int imatch_features_pack_u8_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev) {
-    return features_pack<uint8_t>(ctx, f, src_dev);
+    HIP_TRY(ctx, hipMemsetAsync(f->flag, 0, 256, ctx->stream));
+    const unsigned grid = (unsigned)((f->n_pad + 3) / 4);
+    hipLaunchKernelGGL(pack_rows_kernel<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, src_dev, f->n, f->n_pad, f->desc,
+                       f->norm, f->hneg, f->flag);
+    HIP_TRY(ctx, hipGetLastError());
+    f->integral = 1;
+    return IMATCH_OK;
 }
 
 template <typename T>
@@ -579,13 +586,9 @@ int imatch_features_is_integral(const imatch_features* f) { return f ? f->integr
 void imatch_features_free(imatch_features* f) {
     if (!f) return;
     if (f->ctx) {
-        (void)hipSetDevice(f->ctx->device);
-        (void)hipStreamSynchronize(f->ctx->stream);
+        imatch_pool_free(f->ctx, f->desc);
+        imatch_pool_free(f->ctx, f->image);
     }
-    if (f->desc) (void)hipFree(f->desc);
-    if (f->norm) (void)hipFree(f->norm);
-    if (f->flag) (void)hipFree(f->flag);
-    if (f->image) (void)hipFree(f->image);
     free(f->kp);
     free(f);
 }
@@ -599,8 +602,8 @@ int imatch_knn2(imatch_ctx* ctx, const imatch_features* q, const imatch_features
     if (!ctx || !q || !t || (q->n > 0 && (!idx || !dist))) return imatch_set_err(ctx, IMATCH_EINVAL, "null argument");
     if (q->n == 0) return IMATCH_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int4* out_dev = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&out_dev, (size_t)q->n * 16));
+    int4* out_dev = (int4*)imatch_pool_alloc(ctx, (size_t)q->n * 16);
+    if (!out_dev) return imatch_set_err(ctx, IMATCH_ENOMEM, "result list for %lld queries", (long long)q->n);
     int rc = knn2_run(ctx, q, t, 0, (int32_t*)out_dev);
     if (rc == IMATCH_OK) rc = imatch_hs_reserve(ctx, (size_t)q->n * 16);
     if (rc == IMATCH_OK) {
@@ -608,7 +611,7 @@ int imatch_knn2(imatch_ctx* ctx, const imatch_features* q, const imatch_features
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = imatch_set_err(ctx, IMATCH_EHIP, "knn2 download: %s", hipGetErrorString(e));
     }
-    (void)hipFree(out_dev);
+    imatch_pool_free(ctx, out_dev);
     if (rc) return rc;
     const int32_t* o = (const int32_t*)ctx->hs;
     for (int64_t i = 0; i < q->n; ++i) {
@@ -639,16 +642,16 @@ int imatch_ratio_dev(imatch_ctx* ctx, const int32_t* out4_dev, int64_t nq, doubl
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // workspace: gq, gt, gd (nq each) + counter; placed after any knn partials are consumed (same stream)
     const size_t arr = ((size_t)nq * 4 + 255) & ~(size_t)255;
-    char* dev = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&dev, 3 * arr + 256));
+    char* dev = (char*)imatch_pool_alloc(ctx, 3 * arr + 256);
+    if (!dev) return imatch_set_err(ctx, IMATCH_ENOMEM, "match lists for %lld queries", (long long)nq);
     int rc = imatch_hs_reserve(ctx, 3 * arr + 256);
-    if (rc) { (void)hipFree(dev); return rc; }
+    if (rc) { imatch_pool_free(ctx, dev); return rc; }
     hipLaunchKernelGGL(ratio_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int4*)out4_dev, nq, ratio, (int*)dev,
                        (int*)(dev + arr), (float*)(dev + 2 * arr), (unsigned long long*)(dev + 3 * arr));
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->hs, dev, 3 * arr + 256, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dev);
+    imatch_pool_free(ctx, dev);
     if (e != hipSuccess) return imatch_set_err(ctx, IMATCH_EHIP, "ratio: %s", hipGetErrorString(e));
     const char* hsrc = (const char*)ctx->hs;
     const int64_t g = (int64_t)*(const unsigned long long*)(hsrc + 3 * arr);

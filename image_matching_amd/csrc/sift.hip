@@ -56,6 +56,7 @@ struct imatch_sift_state {
     size_t arena_bytes;
     PyrTable T;
     int h, w;
+    int ref_hint, kp_hint;  // list lengths of the previous extraction: launch-grid and download-size guesses
 };
 
 void imatch_sift_state_free(imatch_ctx* ctx) {
@@ -369,20 +370,20 @@ detect_kernel_generic(PyrTable T, int o, float thr, uint2* __restrict__ cand, in
 }
 
 // nOctaveLayers = 3 (5 DoG layers), the default: a streaming scan with no LDS and no barrier. A wave
-// owns a strip of 62 output columns (lanes 0 and 63 carry the halo columns) and walks 32 output rows;
+// owns a strip of 62 output columns (lanes 0 and 63 carry the halo columns) and walks `rpw` output rows
+// (32 on a map: 6% halo re-reads; 8 on a camera frame, where the walk's serial load latency is the cost);
 // per row and layer it loads ONE value per lane (a coalesced 256-byte row segment), gets the left and
 // right neighbours from the adjacent lanes, and keeps a 3-row window of horizontal max/min in
 // registers. Instead of 26 compares per pixel and layer, every layer's 3x3 max and min are built
 // separably and shared by the three layers that need them: val is a maximum iff
 // val >= max(M[i-1], M[i], M[i+1]), with M the 3x3 max that includes val itself.
 #define DS_COLS 62
-#define DS_ROWS 32
 __global__ void __launch_bounds__(256)
-detect_stream_kernel(PyrTable T, int o, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count) {
+detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count) {
     const int cols = T.cols[o], rows = T.rows[o];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = SIFT_IMG_BORDER + blockIdx.x * DS_COLS + lane - 1;
-    const int ry0 = SIFT_IMG_BORDER + (blockIdx.y * 4 + wv) * DS_ROWS;
+    const int ry0 = SIFT_IMG_BORDER + (blockIdx.y * 4 + wv) * rpw;
     __shared__ uint2 stage_all[4][DET_STAGE];
     __shared__ int wcnt[5];
     uint2* stage = stage_all[wv];
@@ -409,7 +410,7 @@ detect_stream_kernel(PyrTable T, int o, float thr, uint2* __restrict__ cand, int
         load_row(ry0 - 1, 0);
         load_row(ry0, 1);
     }
-    for (int k = 0; wave_active && k < DS_ROWS; k += 3) {
+    for (int k = 0; wave_active && k < rpw; k += 3) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int r = ry0 + k + u;            // output row: rows r-1, r, r+1 sit in the three slots
@@ -420,7 +421,7 @@ detect_stream_kernel(PyrTable T, int o, float thr, uint2* __restrict__ cand, int
                 M[l] = fmaxf(fmaxf(hm[l][0], hm[l][1]), hm[l][2]);
                 m[l] = fminf(fminf(hn[l][0], hn[l][1]), hn[l][2]);
             }
-            const bool row_ok = col_ok && k + u < DS_ROWS && r < rows - SIFT_IMG_BORDER;
+            const bool row_ok = col_ok && k + u < rpw && r < rows - SIFT_IMG_BORDER;
 #pragma unroll
             for (int i = 1; i <= 3; ++i) {
                 const float val = cv[i - 1][(u + 1) % 3];
@@ -449,12 +450,8 @@ __device__ __forceinline__ void solve3(const float a[3][3], const float b[3], fl
                 b[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]));
 }
 
-__global__ void __launch_bounds__(256)
-refine_kernel(PyrTable T, const uint2* __restrict__ cand, int n_cand, float contrast_thr, float edge_thr, float sigma,
-              RefinedKp* __restrict__ out, int* __restrict__ count) {
-    const int id = blockIdx.x * 256 + threadIdx.x;
-    if (id >= n_cand) return;
-    const uint2 cd = cand[id];
+__device__ __forceinline__ bool refine_one(const PyrTable& T, const uint2 cd, float contrast_thr, float edge_thr,
+                                           float sigma, RefinedKp& k) {
     const int octv = cd.x >> 8;
     int layer = cd.x & 255, r = cd.y >> 16, c = cd.y & 0xffff;
     const int nl = T.nl, rows = T.rows[octv], cols = T.cols[octv];
@@ -482,13 +479,13 @@ refine_kernel(PyrTable T, const uint2* __restrict__ cand, int n_cand, float cont
         solve3(H, dD, X);
         xi = -X[2]; xr = -X[1]; xc = -X[0];
         if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
-        if (fabsf(xi) > (float)(INT_MAX / 3) || fabsf(xr) > (float)(INT_MAX / 3) || fabsf(xc) > (float)(INT_MAX / 3)) return;
+        if (fabsf(xi) > (float)(INT_MAX / 3) || fabsf(xr) > (float)(INT_MAX / 3) || fabsf(xc) > (float)(INT_MAX / 3)) return false;
         c += __float2int_rn(xc); r += __float2int_rn(xr); layer += __float2int_rn(xi);
         if (layer < 1 || layer > nl || c < SIFT_IMG_BORDER || c >= cols - SIFT_IMG_BORDER || r < SIFT_IMG_BORDER ||
             r >= rows - SIFT_IMG_BORDER)
-            return;
+            return false;
     }
-    if (i >= SIFT_MAX_INTERP_STEPS) return;
+    if (i >= SIFT_MAX_INTERP_STEPS) return false;
     float contr;
     {
         const float* img = T.dog[octv][layer];
@@ -499,23 +496,34 @@ refine_kernel(PyrTable T, const uint2* __restrict__ cand, int n_cand, float cont
                              (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
         const float t = dD[0] * xc + dD[1] * xr + dD[2] * xi;
         contr = AT(img, r, c) * img_scale + t * 0.5f;
-        if (fabsf(contr) * nl < contrast_thr) return;
+        if (fabsf(contr) * nl < contrast_thr) return false;
         const float v2 = AT(img, r, c) * 2.f;
         const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_deriv_scale;
         const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_deriv_scale;
         const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_deriv_scale;
         const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
-        if (det <= 0 || tr * tr * edge_thr >= (edge_thr + 1) * (edge_thr + 1) * det) return;
+        if (det <= 0 || tr * tr * edge_thr >= (edge_thr + 1) * (edge_thr + 1) * det) return false;
     }
 #undef AT
-    RefinedKp k;
     k.x = (c + xc) * (1 << octv);
     k.y = (r + xr) * (1 << octv);
     k.octave = octv + (layer << 8) + ((int)rint(((double)xi + 0.5) * 255) << 16);
     k.size = sigma * powf(2.f, (layer + xi) / nl) * (1 << octv) * 2;
     k.response = fabsf(contr);
     k.o = octv; k.layer = layer; k.r = r; k.c = c;
-    out[atomicAdd(count, 1)] = k;
+    return true;
+}
+
+// The candidate count is read from device memory (the scan that produced it is still in flight when the
+// host queues this kernel), so the grid is sized by a guess and strides.
+__global__ void __launch_bounds__(256)
+refine_kernel(PyrTable T, const uint2* __restrict__ cand, const int* __restrict__ n_cand_dev, int cap, float contrast_thr,
+              float edge_thr, float sigma, RefinedKp* __restrict__ out, int* __restrict__ count) {
+    const int n_cand = min(*n_cand_dev, cap);
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < n_cand; id += gridDim.x * 256) {
+        RefinedKp k;
+        if (refine_one(T, cand[id], contrast_thr, edge_thr, sigma, k)) out[atomicAdd(count, 1)] = k;
+    }
 }
 
 __device__ __forceinline__ float atan2_deg(float y, float x) {
@@ -525,12 +533,12 @@ __device__ __forceinline__ float atan2_deg(float y, float x) {
 }
 
 // ---- calcOrientationHist + peak picking: one wavefront per refined keypoint ---------------------
-// A wave walks `kpw` consecutive keypoints (1 for a frame, so the launch stays wide; up to 8 for a
-// map) and stages its output records, so the output counter sees one atomicAdd per workgroup.
+// The list length is read from device memory and the grid strides over it; a wave stages its output
+// records, so the output counter sees one atomicAdd per workgroup.
 #define ORI_STAGE 64
 __global__ void __launch_bounds__(256)
-orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, int n_ref, int kpw, KpRec* __restrict__ out, int cap,
-              int* __restrict__ count) {
+orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restrict__ n_ref_dev, int ref_cap,
+              KpRec* __restrict__ out, int cap, int* __restrict__ count) {
     __shared__ unsigned long long hacc[4][SIFT_ORI_HIST_BINS];
     __shared__ float hsm[4][SIFT_ORI_HIST_BINS + 4];
     __shared__ KpRec stage_all[4][ORI_STAGE];
@@ -539,8 +547,9 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, int n_ref, int kpw,
     const int n = SIFT_ORI_HIST_BINS;
     KpRec* stage = stage_all[wave];
     int n_staged = 0;
-    for (int t = 0; t < kpw; ++t) {
-        const int id = (blockIdx.x * 4 + wave) * kpw + t;
+    const int n_ref = min(*n_ref_dev, ref_cap);
+    for (int base = blockIdx.x * 4; base < n_ref; base += gridDim.x * 4) {  // workgroup-uniform trip count
+        const int id = base + wave;
         const bool active = id < n_ref;
         if (lane < n) hacc[wave][lane] = 0ull;
         __syncthreads();
@@ -645,8 +654,16 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, int n_kp, int first_o
         radius = min(radius, (int)sqrt(((double)cols) * cols + ((double)rows) * rows));
         cos_t /= hist_width;
         sin_t /= hist_width;
-        const int side = 2 * radius + 1;
-        for (int p = lane; p < side * side; p += 64) {
+        const int side = 2 * radius + 1, total = side * side;
+        // Lanes of one instruction must not sit on neighbouring pixels: those fall into the same spatial cell
+        // and similar orientation bins, and same-address LDS atomics serialise (that was 2/3 of this kernel).
+        // total is odd, so multiplying the sample number by a power of two is a bijection mod total; one near
+        // 0.3*total sends consecutive lanes to different bands of the patch. Sums are fixed-point, so the
+        // visiting order does not change a single bit of the result.
+        int spread = 1;
+        while (spread * 4 <= total) spread <<= 1;
+        for (int q = lane; q < total; q += 64) {
+            const int p = (int)(((unsigned)q * (unsigned)spread) % (unsigned)total);
             const int i = p / side - radius, j = p % side - radius;
             const float c_rot = j * cos_t - i * sin_t;
             const float r_rot = j * sin_t + i * cos_t;
@@ -784,13 +801,46 @@ static bool kp_less(const KpRec& a, const KpRec& b) {  // KeyPoint12_LessThan (k
     return false;
 }
 
-static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
-
-static int read_counter(imatch_ctx* ctx, const int* dev, int* host) {
-    HIP_TRY(ctx, hipMemcpyAsync(host, dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return IMATCH_OK;
+// Sort by KeyPoint12_LessThan. (x, y) decide almost every comparison, so the records are radix-sorted
+// (LSD, 11-bit digits) on the 64-bit key made of the two floats' order-preserving bit patterns, and only
+// runs of equal (x, y) - the several orientations of one point - go through the full comparator.
+static void sort_keypoints(const KpRec* in, int n, KpRec* out) {
+    auto ord = [](float f) {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    };
+    std::vector<uint64_t> key((size_t)n), key2((size_t)n);
+    std::vector<uint32_t> idx((size_t)n), idx2((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        key[i] = ((uint64_t)ord(in[i].x) << 32) | ord(in[i].y);
+        idx[i] = (uint32_t)i;
+    }
+    for (int shift = 0; shift < 64; shift += 11) {
+        uint32_t hist[2049] = {0};
+        for (int i = 0; i < n; ++i) hist[((key[i] >> shift) & 2047) + 1]++;
+        bool single = false;
+        for (int d = 1; d <= 2048; ++d) single = single || hist[d] == (uint32_t)n;
+        if (single) continue;
+        for (int d = 1; d <= 2048; ++d) hist[d] += hist[d - 1];
+        for (int i = 0; i < n; ++i) {
+            const uint32_t at = hist[(key[i] >> shift) & 2047]++;
+            key2[at] = key[i];
+            idx2[at] = idx[i];
+        }
+        key.swap(key2);
+        idx.swap(idx2);
+    }
+    for (int i = 0; i < n; ++i) out[i] = in[idx[i]];
+    for (int i = 0; i < n;) {
+        int j = i + 1;
+        while (j < n && key[j] == key[i]) ++j;
+        if (j - i > 1) std::sort(out + i, out + j, kp_less);
+        i = j;
+    }
 }
+
+static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 
 extern "C" {
 
@@ -906,9 +956,12 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             }
             if (rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER) {
                 const int iw = cols - 2 * SIFT_IMG_BORDER, ih = rows - 2 * SIFT_IMG_BORDER;
-                if (nl == 3)
-                    hipLaunchKernelGGL(detect_stream_kernel, dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * DS_ROWS - 1) / (4 * DS_ROWS)),
-                                       dim3(256), 0, ctx->stream, T, o, thr, d_cand, cap, d_cnt);
+                if (nl == 3) {
+                    const size_t px = (size_t)iw * ih;
+                    const int rpw = px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
+                    hipLaunchKernelGGL(detect_stream_kernel, dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * rpw - 1) / (4 * rpw)),
+                                       dim3(256), 0, ctx->stream, T, o, rpw, thr, d_cand, cap, d_cnt);
+                }
                 else
                     hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H), dim3(256),
                                        0, ctx->stream, T, o, thr, d_cand, cap, d_cnt);
@@ -916,40 +969,45 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         }
         HIP_TRY(ctx, hipGetLastError());
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
-        int n_cand = 0;
-        rc = read_counter(ctx, d_cnt, &n_cand);
+        // ---- refine + orientation are queued behind the scan without waiting for its count
+        hipLaunchKernelGGL(refine_kernel, dim3(std::min((cap + 255) / 256, 1024)), dim3(256), 0, ctx->stream, T,
+                           (const uint2*)d_cand, (const int*)d_cnt, cap, (float)P->contrast_threshold,
+                           (float)P->edge_threshold, (float)P->sigma, d_ref, d_cnt + 1);
+        const int ref_hint = S->ref_hint > 0 ? S->ref_hint : 4096;
+        hipLaunchKernelGGL(orient_kernel, dim3(std::min(std::max((ref_hint + 3) / 4, 64), 4096)), dim3(256), 0, ctx->stream,
+                           T, (const RefinedKp*)d_ref, (const int*)(d_cnt + 1), cap, d_kp, 2 * cap, d_cnt + 2);
+        HIP_TRY(ctx, hipGetLastError());
+        // ---- the extraction's one synchronisation: the three counters and (a guess of) the records
+        const int kp_hint = std::min(2 * cap, S->kp_hint > 0 ? S->kp_hint : 8192);
+        rc = imatch_hs_reserve(ctx, 256 + (size_t)kp_hint * sizeof(KpRec));
         if (rc) return rc;
+        int* h_cnt = (int*)ctx->hs;
+        KpRec* h_kp = (KpRec*)((char*)ctx->hs + 256);
+        HIP_TRY(ctx, hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h_kp, d_kp, (size_t)kp_hint * sizeof(KpRec), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const int n_cand = h_cnt[0], n_ref = h_cnt[1], n_kp = h_cnt[2];
         if (n_cand > cap) {  // rare: grow the lists and run the frame again
             cap = n_cand + n_cand / 8;
             continue;
         }
-        int n_ref = 0, n_kp = 0;
-        if (n_cand > 0) {
-            hipLaunchKernelGGL(refine_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, ctx->stream, T, (const uint2*)d_cand,
-                               n_cand, (float)P->contrast_threshold, (float)P->edge_threshold, (float)P->sigma, d_ref,
-                               d_cnt + 1);
-            HIP_TRY(ctx, hipGetLastError());
-            rc = read_counter(ctx, d_cnt + 1, &n_ref);
-            if (rc) return rc;
+        if (n_kp > 2 * cap) {
+            cap = n_kp;
+            continue;
         }
-        if (n_ref > 0) {
-            const int kpw = std::min(8, std::max(1, n_ref / 8192));  // keypoints per wave: >= 2048 workgroups first
-            hipLaunchKernelGGL(orient_kernel, dim3((n_ref + 4 * kpw - 1) / (4 * kpw)), dim3(256), 0, ctx->stream, T,
-                               (const RefinedKp*)d_ref, n_ref, kpw, d_kp, 2 * cap, d_cnt + 2);
-            HIP_TRY(ctx, hipGetLastError());
-            rc = read_counter(ctx, d_cnt + 2, &n_kp);
+        S->ref_hint = n_ref + n_ref / 4 + 256;
+        S->kp_hint = n_kp + n_kp / 4 + 1024;
+        if (n_kp > kp_hint) {
+            rc = imatch_hs_reserve(ctx, 256 + (size_t)n_kp * sizeof(KpRec));  // may move hs: copy everything again
             if (rc) return rc;
-            if (n_kp > 2 * cap) {
-                cap = n_kp;
-                continue;
-            }
+            h_kp = (KpRec*)((char*)ctx->hs + 256);
+            HIP_TRY(ctx, hipMemcpyAsync(h_kp, d_kp, (size_t)n_kp * sizeof(KpRec), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
         // ---- removeDuplicatedSorted + first-octave rescale on the host (K records of 24 bytes)
         std::vector<KpRec> kps((size_t)n_kp);
         if (n_kp > 0) {
-            HIP_TRY(ctx, hipMemcpyAsync(kps.data(), d_kp, (size_t)n_kp * sizeof(KpRec), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            std::sort(kps.begin(), kps.end(), kp_less);
+            sort_keypoints(h_kp, n_kp, kps.data());
             size_t j = 0;
             for (size_t i = 1; i < kps.size(); ++i) {
                 const KpRec &a = kps[j], &b = kps[i];
@@ -973,7 +1031,8 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             p[5] = (float)kps[i].octave; p[6] = -1.f;
         }
         if (P->clahe) {
-            if (hipMalloc((void**)&f->image, (size_t)h * w) != hipSuccess) {
+            f->image = (uint8_t*)imatch_pool_alloc(ctx, (size_t)h * w);
+            if (!f->image) {
                 imatch_features_free(f);
                 return imatch_set_err(ctx, IMATCH_ENOMEM, "image copy");
             }
@@ -989,12 +1048,14 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             continue;
         }
         if (K > 0) {
-            HIP_TRY(ctx, hipMemcpyAsync(d_sorted, kps.data(), (size_t)K * sizeof(KpRec), hipMemcpyHostToDevice, ctx->stream));
+            // staged in the pinned block (K <= n_kp records fit), which nothing rewrites before the next synchronisation
+            memcpy(h_kp, kps.data(), (size_t)K * sizeof(KpRec));
+            HIP_TRY(ctx, hipMemcpyAsync(d_sorted, h_kp, (size_t)K * sizeof(KpRec), hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(describe_kernel, dim3((K + 3) / 4), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted, K,
                                first_octave, d_desc);
             HIP_TRY(ctx, hipGetLastError());
         }
-        rc = imatch_features_pack_u8_dev(ctx, f, d_desc);  // bf16 rows + norms; synchronises (kps stays alive until here)
+        rc = imatch_features_pack_u8_dev(ctx, f, d_desc);  // bf16 rows + norms, queued (u8 rows are integral by type)
         if (rc) { imatch_features_free(f); return rc; }
         *out = f;
         return IMATCH_OK;
