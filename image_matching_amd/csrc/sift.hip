@@ -67,6 +67,8 @@ void imatch_sift_state_free(imatch_ctx* ctx) {
 }
 
 __device__ __forceinline__ int reflect101(int p, int len) {
+    if (p < 0) p = -p;                       // one fold each way covers every halo narrower than the image
+    if (p >= len) p = 2 * (len - 1) - p;
     if ((unsigned)p < (unsigned)len) return p;
     if (len == 1) return 0;
     while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
@@ -152,10 +154,21 @@ blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __res
             }
         }
     } else {
-        for (int f = tid; f < H2 * P; f += 256) {
+        // all of a thread's loads are issued before its first LDS write here too: on a camera frame the
+        // border tiles are what the launch waits for
+        constexpr int NE = (H2 * P + 255) / 256;
+        float e[NE];
+#pragma unroll
+        for (int it = 0; it < NE; ++it) {
+            const int f = min(tid + it * 256, H2 * P - 1);
             const int yp = f / (2 * P), rem = f - yp * (2 * P);
             const int col = rem >> 1, row = 2 * yp + (rem & 1);
-            in[f] = src[(size_t)reflect101(y0 - R + row, rows) * cols + reflect101(x0 - XO + col, cols)];
+            e[it] = src[(size_t)reflect101(y0 - R + row, rows) * cols + reflect101(x0 - XO + col, cols)];
+        }
+#pragma unroll
+        for (int it = 0; it < NE; ++it) {
+            const int f = tid + it * 256;
+            if (f < H2 * P) in[f] = e[it];
         }
     }
     __syncthreads();
@@ -268,22 +281,28 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// wave-uniform n_staged > 0 or == 0; the whole wave calls
+template <typename Rec>
+__device__ __forceinline__ void stage_flush_wave(Rec* stage, int& n_staged, Rec* out, int cap, int* count) {
+    if (n_staged == 0) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, n_staged);
+    base = __shfl(base, 0);
+    wave_lds_fence();
+    for (int j = lane; j < n_staged; j += 64)
+        if (base + j < cap) out[base + j] = stage[j];
+    wave_lds_fence();
+    n_staged = 0;
+}
+
 template <typename Rec, int STAGE>
 __device__ __forceinline__ void stage_append(Rec* stage, int& n_staged, bool hit, const Rec& rec, Rec* out, int cap,
                                              int* count) {
     const unsigned long long mk = __ballot(hit);
     if (mk == 0) return;  // wave-uniform
     const int lane = threadIdx.x & 63, np = __popcll(mk);
-    if (n_staged + np > STAGE) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(count, n_staged);
-        base = __shfl(base, 0);
-        wave_lds_fence();
-        for (int j = lane; j < n_staged; j += 64)
-            if (base + j < cap) out[base + j] = stage[j];
-        wave_lds_fence();
-        n_staged = 0;
-    }
+    if (n_staged + np > STAGE) stage_flush_wave(stage, n_staged, out, cap, count);
     if (hit) stage[n_staged + __popcll(mk & ((1ull << lane) - 1ull))] = rec;
     n_staged += np;
 }
@@ -434,6 +453,124 @@ detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ 
         }
     }
     stage_flush_block(stage, n_staged, wcnt, cand, cap, count);
+}
+
+// ---- the small octaves: one workgroup, LDS-resident ----------------------------------------------
+// From the first octave of at most TAIL_MAXPX pixels on (60x80 for a 640x480 frame) a launch per layer
+// is all latency: 7 launches per octave for a few thousand pixels. One 1024-thread workgroup instead
+// walks those octaves start to finish: the current Gaussian layer, the row-pass intermediate and a
+// ring of three DoG layers live in LDS; every layer is also written to the global pyramid (refine,
+// orientation and descriptors read it there). Same ascending-tap fma chains, same reflect-101, same
+// extremum predicate as the per-layer kernels, so the result is bit-identical to them.
+#define TAIL_MAXPX 4800
+#define TAIL_STAGE 64
+struct TailK { int r[MAX_LAY]; float k[MAX_LAY][2 * RT_MAXR + 1]; };  // slot i = blur that makes layer i
+#define TAIL_LDS_BYTES ((6 * TAIL_MAXPX + TAIL_MAXPX / 4 + 64) * 4 + 16 * TAIL_STAGE * 8)
+
+__global__ void __launch_bounds__(1024)
+pyramid_tail_kernel(PyrTable T, int o_start, TailK gk, float thr, uint2* __restrict__ cand, int cap,
+                    int* __restrict__ count) {
+    extern __shared__ float smem[];
+    float* const g0 = smem;
+    float* const tm = smem + 2 * TAIL_MAXPX;
+    float* const dg = smem + 3 * TAIL_MAXPX;                // ring of 3 DoG layers
+    float* const nx = smem + 6 * TAIL_MAXPX;                // next octave's layer 0
+    float* const kt = nx + TAIL_MAXPX / 4;                  // taps of the current blur
+    uint2* const stage = (uint2*)(kt + 64) + (threadIdx.x >> 6) * TAIL_STAGE;
+    const int tid = threadIdx.x, nl = T.nl;
+    int n_staged = 0;
+    for (int o = o_start; o < T.n_oct; ++o) {
+        const int rows = T.rows[o], cols = T.cols[o], n = rows * cols;
+        if (o == o_start) {
+            const float* up = T.gauss[o - 1][nl];
+            const int ucols = T.cols[o - 1];
+            for (int p = tid; p < n; p += 1024) {
+                const int y = p / cols, x = p - y * cols;
+                const float v = up[(size_t)(2 * y) * ucols + 2 * x];
+                g0[p] = v;
+                T.gauss[o][0][p] = v;
+            }
+        } else {
+            for (int p = tid; p < n; p += 1024) {
+                const float v = nx[p];
+                g0[p] = v;
+                T.gauss[o][0][p] = v;
+            }
+        }
+        __syncthreads();
+        int cur = 0;
+        const int ncols2 = cols >> 1, nrows2 = rows >> 1;
+        const bool has_next = o + 1 < T.n_oct;
+        for (int i = 1; i < nl + 3; ++i) {
+            const int R = gk.r[i], N = 2 * R + 1;
+            if (tid < N) kt[tid] = gk.k[i][tid];
+            __syncthreads();
+            const float* src = g0 + cur * TAIL_MAXPX;
+            float* dst = g0 + (cur ^ 1) * TAIL_MAXPX;
+            for (int p = tid; p < n; p += 1024) {
+                const int y = p / cols, x = p - y * cols;
+                const float* srow = src + y * cols;
+                float acc = 0.f;
+                for (int t = 0; t < N; ++t) acc = fmaf(kt[t], srow[reflect101(x + t - R, cols)], acc);
+                tm[p] = acc;
+            }
+            __syncthreads();  // also: every detect below has finished reading the ring slot rewritten next
+            float* dslot = dg + ((i - 1) % 3) * TAIL_MAXPX;
+            float* gout = T.gauss[o][i];
+            float* dout = T.dog[o][i - 1];
+            for (int p = tid; p < n; p += 1024) {
+                const int y = p / cols, x = p - y * cols;
+                float acc = 0.f;
+                for (int t = 0; t < N; ++t) acc = fmaf(kt[t], tm[reflect101(y + t - R, rows) * cols + x], acc);
+                dst[p] = acc;
+                gout[p] = acc;
+                const float dv = acc - src[p];
+                dslot[p] = dv;
+                dout[p] = dv;
+                if (i == nl && has_next && !(y & 1) && !(x & 1) && (y >> 1) < nrows2 && (x >> 1) < ncols2)
+                    nx[(y >> 1) * ncols2 + (x >> 1)] = acc;
+            }
+            __syncthreads();
+            cur ^= 1;
+            const int j = i - 2;  // DoG layers j-1, j, j+1 are in the ring: scan layer j
+            if (j >= 1 && rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER) {
+                const int iw = cols - 2 * SIFT_IMG_BORDER, ih = rows - 2 * SIFT_IMG_BORDER, ni = iw * ih;
+                const float* lp = dg + ((j - 1) % 3) * TAIL_MAXPX;
+                const float* lc = dg + (j % 3) * TAIL_MAXPX;
+                const float* ln = dg + ((j + 1) % 3) * TAIL_MAXPX;
+                for (int base = 0; base < ni; base += 1024) {  // workgroup-uniform trip count
+                    const int p = base + tid;
+                    bool hit = false;
+                    int r = 0, c = 0;
+                    if (p < ni) {
+                        r = SIFT_IMG_BORDER + p / iw;
+                        c = SIFT_IMG_BORDER + p % iw;
+                        const int q = r * cols + c;
+                        const float val = lc[q];
+                        if (fabsf(val) > thr) {
+                            bool is_max = val > 0, is_min = val < 0;
+#pragma unroll
+                            for (int dr = -1; dr <= 1; ++dr) {
+#pragma unroll
+                                for (int dc = -1; dc <= 1; ++dc) {
+                                    const int qq = q + dr * cols + dc;
+                                    const float a = lc[qq], b = lp[qq], d = ln[qq];
+                                    is_max = is_max && val >= a && val >= b && val >= d;
+                                    is_min = is_min && val <= a && val <= b && val <= d;
+                                }
+                            }
+                            hit = is_max || is_min;
+                        }
+                    }
+                    stage_append<uint2, TAIL_STAGE>(stage, n_staged, hit,
+                                                    make_uint2((unsigned)((o << 8) | j), (unsigned)((r << 16) | c)), cand, cap,
+                                                    count);
+                }
+            }
+        }
+        __syncthreads();  // nx and the ring are rewritten by the next octave
+    }
+    stage_flush_wave(stage, n_staged, cand, cap, count);
 }
 
 // ---- adjustLocalExtrema ---------------------------------------------------------------------------
@@ -945,7 +1082,10 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             sig[i] = sqrt(sig_total * sig_total - sig_prev * sig_prev);
         }
         const float thr = (float)(int)floor(0.5 * P->contrast_threshold / nl * 255);
-        for (int o = 0; o < n_oct; ++o) {
+        // octaves from o_tail on go to the single-workgroup kernel
+        int o_tail = n_oct;
+        for (int o = n_oct - 1; o >= 1 && (size_t)T.rows[o] * T.cols[o] <= TAIL_MAXPX; --o) o_tail = o;
+        for (int o = 0; o < o_tail; ++o) {
             const int rows = T.rows[o], cols = T.cols[o];
             if (o > 0)
                 hipLaunchKernelGGL(decimate_kernel, dim3((cols + 63) / 64, (rows + 3) / 4), dim3(256), 0, ctx->stream,
@@ -966,6 +1106,23 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                     hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H), dim3(256),
                                        0, ctx->stream, T, o, thr, d_cand, cap, d_cnt);
             }
+        }
+        if (o_tail < n_oct) {
+            TailK tk;
+            memset(&tk, 0, sizeof(tk));
+            for (int i = 1; i < nl + 3; ++i) {
+                const int n = gauss_kernel(sig[i], tk.k[i], 2 * RT_MAXR + 1);
+                if (n < 0) return imatch_set_err(ctx, IMATCH_ESIZE, "Gaussian sigma %g needs a kernel wider than %d", sig[i], 2 * RT_MAXR + 1);
+                tk.r[i] = n / 2;
+            }
+            static bool attr_set[64] = {false};
+            if (!attr_set[ctx->device & 63]) {
+                HIP_TRY(ctx, hipFuncSetAttribute((const void*)pyramid_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 TAIL_LDS_BYTES));
+                attr_set[ctx->device & 63] = true;
+            }
+            hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1), dim3(1024), TAIL_LDS_BYTES, ctx->stream, T, o_tail, tk, thr,
+                               d_cand, cap, d_cnt);
         }
         HIP_TRY(ctx, hipGetLastError());
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
