@@ -57,11 +57,21 @@ struct imatch_sift_state {
     PyrTable T;
     int h, w;
     int ref_hint, kp_hint;  // list lengths of the previous extraction: launch-grid and download-size guesses
+    // Layers nl+1, nl+2 and the extremum scan of an octave are not needed by the next octave: they run
+    // on this second stream, forked after layer nl and joined before the refinement.
+    hipStream_t side;
+    hipEvent_t ev_fork[MAX_OCT], ev_join;
 };
 
 void imatch_sift_state_free(imatch_ctx* ctx) {
     if (!ctx || !ctx->sift) return;
     if (ctx->sift->arena) (void)hipFree(ctx->sift->arena);
+    if (ctx->sift->side) {
+        (void)hipStreamSynchronize(ctx->sift->side);
+        for (int i = 0; i < MAX_OCT; ++i) (void)hipEventDestroy(ctx->sift->ev_fork[i]);
+        (void)hipEventDestroy(ctx->sift->ev_join);
+        (void)hipStreamDestroy(ctx->sift->side);
+    }
     free(ctx->sift);
     ctx->sift = nullptr;
 }
@@ -893,34 +903,36 @@ static int gauss_kernel(double sigma, float* k, int maxn) {
 }
 
 template <int R>
-static void launch_blur_fixed(imatch_ctx* ctx, const float* src, float* dst, float* dog, int rows, int cols, const float* k) {
+static void launch_blur_fixed(hipStream_t st, const float* src, float* dst, float* dog, int rows, int cols, const float* k) {
     GK<R> gk;
     memcpy(gk.k, k, sizeof(gk.k));
-    hipLaunchKernelGGL(blur_kernel<R>, dim3((cols + 63) / 64, (rows + 31) / 32), dim3(256), 0, ctx->stream, src, dst, dog,
+    hipLaunchKernelGGL(blur_kernel<R>, dim3((cols + 63) / 64, (rows + 31) / 32), dim3(256), 0, st, src, dst, dog,
                        rows, cols, gk);
 }
 
 // GaussianBlur(src, dst, Size(), sigma) [+ dog = dst - src]; tmp: scratch of the same size (runtime-radius path)
-static int gaussian_blur(imatch_ctx* ctx, const float* src, float* dst, float* dog, float* tmp, int rows, int cols,
-                         double sigma) {
+static bool blur_radius_is_templated(int r) { return r == 4 || r == 5 || r == 6 || r == 8 || r == 10 || r == 13; }
+
+static int gaussian_blur(imatch_ctx* ctx, hipStream_t st, const float* src, float* dst, float* dog, float* tmp, int rows,
+                         int cols, double sigma) {
     float k[2 * RT_MAXR + 1];
     const int n = gauss_kernel(sigma, k, 2 * RT_MAXR + 1);
     if (n < 0) return imatch_set_err(ctx, IMATCH_ESIZE, "Gaussian sigma %g needs a kernel wider than %d", sigma, 2 * RT_MAXR + 1);
     const int r = n / 2;
     switch (r) {
-        case 4: launch_blur_fixed<4>(ctx, src, dst, dog, rows, cols, k); break;
-        case 5: launch_blur_fixed<5>(ctx, src, dst, dog, rows, cols, k); break;
-        case 6: launch_blur_fixed<6>(ctx, src, dst, dog, rows, cols, k); break;
-        case 8: launch_blur_fixed<8>(ctx, src, dst, dog, rows, cols, k); break;
-        case 10: launch_blur_fixed<10>(ctx, src, dst, dog, rows, cols, k); break;
-        case 13: launch_blur_fixed<13>(ctx, src, dst, dog, rows, cols, k); break;
+        case 4: launch_blur_fixed<4>(st, src, dst, dog, rows, cols, k); break;
+        case 5: launch_blur_fixed<5>(st, src, dst, dog, rows, cols, k); break;
+        case 6: launch_blur_fixed<6>(st, src, dst, dog, rows, cols, k); break;
+        case 8: launch_blur_fixed<8>(st, src, dst, dog, rows, cols, k); break;
+        case 10: launch_blur_fixed<10>(st, src, dst, dog, rows, cols, k); break;
+        case 13: launch_blur_fixed<13>(st, src, dst, dog, rows, cols, k); break;
         default: {
             GKrt gk;
             gk.r = r;
             memcpy(gk.k, k, sizeof(float) * n);
             const dim3 grid((cols + 63) / 64, (rows + 3) / 4);
-            hipLaunchKernelGGL(blur_rows_rt_kernel, grid, dim3(256), 0, ctx->stream, src, tmp, rows, cols, gk);
-            hipLaunchKernelGGL(blur_cols_rt_kernel, grid, dim3(256), 0, ctx->stream, (const float*)tmp, src, dst, dog, rows,
+            hipLaunchKernelGGL(blur_rows_rt_kernel, grid, dim3(256), 0, st, src, tmp, rows, cols, gk);
+            hipLaunchKernelGGL(blur_cols_rt_kernel, grid, dim3(256), 0, st, (const float*)tmp, src, dst, dog, rows,
                                cols, gk);
         }
     }
@@ -1072,7 +1084,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         hipLaunchKernelGGL(upsample2_kernel, dim3((bcols + 63) / 64, (brows + 3) / 4), dim3(256), 0, ctx->stream, d_src, h,
                            w, w, d_up);
         const float sig_diff = sqrtf(fmaxf((float)P->sigma * (float)P->sigma - 0.5f * 0.5f * 4, 0.01f));
-        int rc = gaussian_blur(ctx, d_up, T.gauss[0][0], nullptr, d_tmp, brows, bcols, sig_diff);
+        int rc = gaussian_blur(ctx, ctx->stream, d_up, T.gauss[0][0], nullptr, d_tmp, brows, bcols, sig_diff);
         if (rc) return rc;
         double sig[MAX_LAY];
         sig[0] = P->sigma;
@@ -1085,13 +1097,36 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // octaves from o_tail on go to the single-workgroup kernel
         int o_tail = n_oct;
         for (int o = n_oct - 1; o >= 1 && (size_t)T.rows[o] * T.cols[o] <= TAIL_MAXPX; --o) o_tail = o;
+        // fork/join (see imatch_sift_state); the runtime-radius blur shares d_tmp, so it stays on one stream
+        // An event record + cross-stream wait costs ~20 us per octave (tools/launch_bench.hip), more than a
+        // camera frame's octave gains; on a map the overlap fills the tails of the big launches.
+        bool use_side = (size_t)brows * bcols >= ((size_t)1 << 22);
+        for (int i = 1; i < nl + 3; ++i) {
+            float kk[2 * RT_MAXR + 1];
+            const int n = gauss_kernel(sig[i], kk, 2 * RT_MAXR + 1);
+            if (n < 0 || !blur_radius_is_templated(n / 2)) use_side = false;
+        }
+        if (use_side && !S->side) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&S->side, hipStreamNonBlocking));
+            for (int i = 0; i < MAX_OCT; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_fork[i], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming));
+        }
+        hipStream_t st2 = use_side ? S->side : ctx->stream;
         for (int o = 0; o < o_tail; ++o) {
             const int rows = T.rows[o], cols = T.cols[o];
             if (o > 0)
                 hipLaunchKernelGGL(decimate_kernel, dim3((cols + 63) / 64, (rows + 3) / 4), dim3(256), 0, ctx->stream,
                                    (const float*)T.gauss[o - 1][nl], T.cols[o - 1], T.gauss[o][0], rows, cols);
-            for (int i = 1; i < nl + 3; ++i) {
-                rc = gaussian_blur(ctx, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i]);
+            for (int i = 1; i <= nl; ++i) {
+                rc = gaussian_blur(ctx, ctx->stream, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i]);
+                if (rc) return rc;
+            }
+            if (use_side) {
+                HIP_TRY(ctx, hipEventRecord(S->ev_fork[o], ctx->stream));
+                HIP_TRY(ctx, hipStreamWaitEvent(st2, S->ev_fork[o], 0));
+            }
+            for (int i = nl + 1; i < nl + 3; ++i) {
+                rc = gaussian_blur(ctx, st2, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i]);
                 if (rc) return rc;
             }
             if (rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER) {
@@ -1100,11 +1135,11 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                     const size_t px = (size_t)iw * ih;
                     const int rpw = px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
                     hipLaunchKernelGGL(detect_stream_kernel, dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * rpw - 1) / (4 * rpw)),
-                                       dim3(256), 0, ctx->stream, T, o, rpw, thr, d_cand, cap, d_cnt);
-                }
-                else
+                                       dim3(256), 0, st2, T, o, rpw, thr, d_cand, cap, d_cnt);
+                } else {
                     hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H), dim3(256),
-                                       0, ctx->stream, T, o, thr, d_cand, cap, d_cnt);
+                                       0, st2, T, o, thr, d_cand, cap, d_cnt);
+                }
             }
         }
         if (o_tail < n_oct) {
@@ -1125,6 +1160,10 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                                d_cand, cap, d_cnt);
         }
         HIP_TRY(ctx, hipGetLastError());
+        if (use_side) {
+            HIP_TRY(ctx, hipEventRecord(S->ev_join, st2));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, S->ev_join, 0));
+        }
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
         // ---- refine + orientation are queued behind the scan without waiting for its count
         hipLaunchKernelGGL(refine_kernel, dim3(std::min((cap + 255) / 256, 1024)), dim3(256), 0, ctx->stream, T,
