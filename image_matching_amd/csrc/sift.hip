@@ -317,19 +317,20 @@ __device__ __forceinline__ void stage_append(Rec* stage, int& n_staged, bool hit
     n_staged += np;
 }
 
-// Every wave of the (4-wave) workgroup must call this, in converged control flow. wcnt: __shared__ int[5].
-template <typename Rec>
+// Every wave of the NW-wave workgroup must call this, in converged control flow. wcnt: __shared__ int[NW + 1].
+template <typename Rec, int NW = 4>
 __device__ __forceinline__ void stage_flush_block(const Rec* stage, int n_staged, int* wcnt, Rec* out, int cap,
                                                   int* count) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) wcnt[wv] = n_staged;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        wcnt[4] = t ? atomicAdd(count, t) : 0;
+        int t = 0;
+        for (int w = 0; w < NW; ++w) t += wcnt[w];
+        wcnt[NW] = t ? atomicAdd(count, t) : 0;
     }
     __syncthreads();
-    int base = wcnt[4];
+    int base = wcnt[NW];
     for (int w = 0; w < wv; ++w) base += wcnt[w];
     for (int j = lane; j < n_staged; j += 64)
         if (base + j < cap) out[base + j] = stage[j];
@@ -581,6 +582,187 @@ pyramid_tail_kernel(PyrTable T, int o_start, TailK gk, float thr, uint2* __restr
         __syncthreads();  // nx and the ring are rewritten by the next octave
     }
     stage_flush_wave(stage, n_staged, cand, cap, count);
+}
+
+// ---- the small octaves, default kernel radii: the same walk, restructured for issue rate -----------
+// pyramid_tail_kernel above spends ~15 instructions per tap (run-time radius, reflect-101 and a tap
+// fetch inside the loop): 237 us for the four small octaves of a 640x480 frame, more than the four
+// large octaves together. With the radii as template parameters the layer sits in LDS with a
+// mirrored margin of TF_M pixels on every side, so no pass reflects; the row pass makes 4 adjacent
+// outputs from aligned 16-byte LDS reads, the column pass 4 stacked outputs from one column walk,
+// all taps unrolled from SGPRs. After each layer the margin is refilled with COPIES of the interior
+// (recomputing a mirrored pixel would visit the taps in mirrored order, which is not bit-identical).
+#define TF_M 13                      // margin rows/columns = largest radius
+#define TF_XO 16                     // column of x = 0 inside a row (>= TF_M, multiple of 4)
+#define TF_EXT 10560                 // floats per margin-extended buffer (60x80 needs 90 x 116, 80x60 110 x 96)
+#define TF_LDS_BYTES ((2 * TF_EXT + 3 * TAIL_MAXPX + TAIL_MAXPX / 4) * 4 + 16 * TAIL_STAGE * 8 + 17 * 4)
+struct TailFK { float k[5][2 * TF_M + 1]; };
+
+__host__ __device__ inline int tf_pitch(int cols) { return (cols + TF_XO + TF_M + 4 + 3) & ~3; }
+__host__ __device__ inline int tf_ext_rows(int rows) { return rows + 2 * TF_M + 4; }
+
+template <int R>
+__device__ __forceinline__ void tf_row_pass(const float* __restrict__ A, float* __restrict__ tm, const float* k, int rows,
+                                            int cols, int P) {
+    constexpr int N = 2 * R + 1, RA = (R + 3) & ~3, OFF = RA - R, NV = (OFF + N + 3 + 3) / 4;
+    const int G = (cols + 3) >> 2, items = (rows + 2 * R) * G;
+    for (int item = threadIdx.x; item < items; item += 1024) {
+        const int yy = item / G, g = item - yy * G;
+        const int row = yy - R + TF_M;                      // buffer row of image row yy - R
+        const float4* src = (const float4*)(A + row * P + TF_XO + 4 * g - RA);
+        float v[NV * 4];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const float4 f = src[q];
+            v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+        }
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const float kk = k[t];
+            a0 = fmaf(kk, v[OFF + t], a0);
+            a1 = fmaf(kk, v[OFF + t + 1], a1);
+            a2 = fmaf(kk, v[OFF + t + 2], a2);
+            a3 = fmaf(kk, v[OFF + t + 3], a3);
+        }
+        *(float4*)(tm + row * P + 4 * g) = make_float4(a0, a1, a2, a3);  // tm columns start at x = 0
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void tf_col_pass(float* __restrict__ A, const float* __restrict__ tm, const float* k, int rows,
+                                            int cols, int P, float* __restrict__ ring, float* __restrict__ gout,
+                                            float* __restrict__ dout, float* __restrict__ nx) {
+    constexpr int N = 2 * R + 1;
+    const int items = ((rows + 3) >> 2) * cols;
+    const int ncols2 = cols >> 1, nrows2 = rows >> 1;
+    for (int item = threadIdx.x; item < items; item += 1024) {
+        const int yg = item / cols, x = item - yg * cols;
+        const int y0 = 4 * yg;
+        const float* col = tm + (y0 - R + TF_M) * P + x;
+        float v[N + 3];
+#pragma unroll
+        for (int j = 0; j < N + 3; ++j) v[j] = col[j * P];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const float kk = k[t];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[jj] = fmaf(kk, v[t + jj], acc[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int y = y0 + jj;
+            if (y >= rows) break;
+            float* a = A + (y + TF_M) * P + TF_XO + x;
+            const float dv = acc[jj] - *a;
+            *a = acc[jj];
+            const int p = y * cols + x;
+            ring[p] = dv;
+            gout[p] = acc[jj];
+            dout[p] = dv;
+            if (nx && !(y & 1) && !(x & 1) && (y >> 1) < nrows2 && (x >> 1) < ncols2) nx[(y >> 1) * ncols2 + (x >> 1)] = acc[jj];
+        }
+    }
+}
+
+// margin <- copies of the interior through reflect-101
+__device__ __forceinline__ void tf_mirror(float* __restrict__ A, int rows, int cols, int P) {
+    const int ew = cols + 2 * TF_M, n = (rows + 2 * TF_M) * ew;
+    for (int p = threadIdx.x; p < n; p += 1024) {
+        const int yy = p / ew, xx = p - yy * ew;
+        const int y = yy - TF_M, x = xx - TF_M;
+        if ((unsigned)y >= (unsigned)rows || (unsigned)x >= (unsigned)cols)
+            A[yy * P + TF_XO + x] = A[(reflect101(y, rows) + TF_M) * P + TF_XO + reflect101(x, cols)];
+    }
+}
+
+template <int R1, int R2, int R3, int R4, int R5>
+__global__ void __launch_bounds__(1024)
+pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* __restrict__ cand, int cap,
+                         int* __restrict__ count) {
+    static_assert(R1 <= TF_M && R2 <= TF_M && R3 <= TF_M && R4 <= TF_M && R5 <= TF_M, "margin too small");
+    extern __shared__ float smem[];
+    float* const A = smem;
+    float* const tm = smem + TF_EXT;
+    float* const dg = smem + 2 * TF_EXT;                    // ring of 3 DoG layers, [rows][cols]
+    float* const nx = dg + 3 * TAIL_MAXPX;                  // next octave's layer 0
+    uint2* const stage = (uint2*)(nx + TAIL_MAXPX / 4) + (threadIdx.x >> 6) * TAIL_STAGE;
+    int* const wcnt = (int*)((uint2*)(nx + TAIL_MAXPX / 4) + 16 * TAIL_STAGE);
+    const int tid = threadIdx.x;
+    int n_staged = 0;
+    for (int o = o_start; o < T.n_oct; ++o) {
+        const int rows = T.rows[o], cols = T.cols[o], n = rows * cols, P = tf_pitch(cols);
+        {
+            const float* up = T.gauss[o - 1][T.nl];
+            const int ucols = T.cols[o - 1];
+            float* g0 = T.gauss[o][0];
+            for (int p = tid; p < n; p += 1024) {
+                const int y = p / cols, x = p - y * cols;
+                const float v = o == o_start ? up[(size_t)(2 * y) * ucols + 2 * x] : nx[p];
+                A[(y + TF_M) * P + TF_XO + x] = v;
+                g0[p] = v;
+            }
+        }
+        __syncthreads();
+        tf_mirror(A, rows, cols, P);
+        __syncthreads();
+        float* const nxo = o + 1 < T.n_oct ? nx : nullptr;
+        const bool scan_ok = rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER;
+        auto scan = [&](int j) {  // DoG layers j-1, j, j+1 sit in the ring
+            if (!scan_ok) return;
+            const int iw = cols - 2 * SIFT_IMG_BORDER, ih = rows - 2 * SIFT_IMG_BORDER, ni = iw * ih;
+            const float* lp = dg + ((j - 1) % 3) * TAIL_MAXPX;
+            const float* lc = dg + (j % 3) * TAIL_MAXPX;
+            const float* ln = dg + ((j + 1) % 3) * TAIL_MAXPX;
+            for (int base = 0; base < ni; base += 1024) {  // workgroup-uniform trip count
+                const int p = base + tid;
+                bool hit = false;
+                int r = 0, c = 0;
+                if (p < ni) {
+                    r = SIFT_IMG_BORDER + p / iw;
+                    c = SIFT_IMG_BORDER + p % iw;
+                    const int q = r * cols + c;
+                    const float val = lc[q];
+                    if (fabsf(val) > thr) {
+                        bool is_max = val > 0, is_min = val < 0;
+#pragma unroll
+                        for (int dr = -1; dr <= 1; ++dr) {
+#pragma unroll
+                            for (int dc = -1; dc <= 1; ++dc) {
+                                const int qq = q + dr * cols + dc;
+                                const float a = lc[qq], b = lp[qq], d = ln[qq];
+                                is_max = is_max && val >= a && val >= b && val >= d;
+                                is_min = is_min && val <= a && val <= b && val <= d;
+                            }
+                        }
+                        hit = is_max || is_min;
+                    }
+                }
+                stage_append<uint2, TAIL_STAGE>(stage, n_staged, hit,
+                                                make_uint2((unsigned)((o << 8) | j), (unsigned)((r << 16) | c)), cand, cap,
+                                                count);
+            }
+        };
+#define TF_LAYER(I, R, NX)                                                                                         \
+        tf_row_pass<R>(A, tm, gk.k[I - 1], rows, cols, P);                                                         \
+        __syncthreads(); /* also: the scan before this is done with the ring slot rewritten next */              \
+        tf_col_pass<R>(A, tm, gk.k[I - 1], rows, cols, P, dg + ((I - 1) % 3) * TAIL_MAXPX, T.gauss[o][I],         \
+                       T.dog[o][I - 1], NX);                                                                       \
+        __syncthreads();                                                                                           \
+        if (I < 5) { tf_mirror(A, rows, cols, P); __syncthreads(); }
+        TF_LAYER(1, R1, nullptr)
+        TF_LAYER(2, R2, nullptr)
+        TF_LAYER(3, R3, nxo)
+        scan(1);
+        TF_LAYER(4, R4, nullptr)
+        scan(2);
+        TF_LAYER(5, R5, nullptr)
+        scan(3);
+#undef TF_LAYER
+        __syncthreads();  // nx, A and the ring are rewritten by the next octave
+    }
+    stage_flush_block<uint2, 16>(stage, n_staged, wcnt, cand, cap, count);
 }
 
 // ---- adjustLocalExtrema ---------------------------------------------------------------------------
@@ -1142,7 +1324,27 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                 }
             }
         }
-        if (o_tail < n_oct) {
+        bool tail_fast = o_tail < n_oct && nl == 3 &&
+                         (size_t)tf_ext_rows(T.rows[o_tail]) * tf_pitch(T.cols[o_tail]) <= TF_EXT;
+        TailFK tfk;
+        memset(&tfk, 0, sizeof(tfk));
+        for (int i = 1; i < nl + 3 && tail_fast; ++i) {
+            static const int want_r[6] = {0, 5, 6, 8, 10, 13};
+            float kk[2 * RT_MAXR + 1];
+            const int n = gauss_kernel(sig[i], kk, 2 * RT_MAXR + 1);
+            if (n / 2 != want_r[i]) tail_fast = false;
+            else memcpy(tfk.k[i - 1], kk, sizeof(float) * n);
+        }
+        if (tail_fast) {
+            static bool attr_set[64] = {false};
+            if (!attr_set[ctx->device & 63]) {
+                HIP_TRY(ctx, hipFuncSetAttribute((const void*)pyramid_tail_fast_kernel<5, 6, 8, 10, 13>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS_BYTES));
+                attr_set[ctx->device & 63] = true;
+            }
+            hipLaunchKernelGGL((pyramid_tail_fast_kernel<5, 6, 8, 10, 13>), dim3(1), dim3(1024), TF_LDS_BYTES, ctx->stream, T,
+                               o_tail, tfk, thr, d_cand, cap, d_cnt);
+        } else if (o_tail < n_oct) {
             TailK tk;
             memset(&tk, 0, sizeof(tk));
             for (int i = 1; i < nl + 3; ++i) {
