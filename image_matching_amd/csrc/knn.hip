@@ -94,7 +94,7 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
     constexpr int STAGE_U4 = TN * 16 + TN / 4;   // uint4 per stage: TN rows x 256 B, then TN f32 (-|t|^2/2)
     constexpr int NT = TN / 32;                  // 32-row tiles per stage
     constexpr int ST_F = QB * 256;               // floats of top-2 state per wave: [QB][b1,b2,i1,i2][64]
-    constexpr int TH_F = QB * 64;                // floats of fetched thresholds per wave: [QB][64]
+    constexpr int TH_F = 3 * QB * 64;            // floats of fetched thresholds per wave: [3][QB][64]
     __shared__ uint4 lds[2 * STAGE_U4 + (4 * ST_F + 4 * 1024 + 4 * TH_F) / 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -131,6 +131,8 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
         st[qb * 256 + 128 + lane] = __int_as_float(-1); st[qb * 256 + 192 + lane] = __int_as_float(-1);
         const int t0 = __hip_atomic_load(gq + qb * 32 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         thl[qb * 64 + lane] = __int_as_float(t0);
+        thl[(QB + qb) * 64 + lane] = __int_as_float(0x7f7f7f7f);
+        thl[(2 * QB + qb) * 64 + lane] = __int_as_float(0x7f7f7f7f);
         G[qb] = -0.5f * ord_f(t0);
     }
 
@@ -164,18 +166,28 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
         if (exchange) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
+                // Chip-wide bound on the query's second-best: the least second-best any list holds, or the
+                // larger of the two least BESTS of the h = 0 and h = 1 lists (disjoint rows, so two rows lie
+                // below it). The second form matters: the two nearest rows rarely sit in the same list, and
+                // min-of-second-bests alone left the bound at about the 13th nearest of what the chip had seen.
                 const float tg = ord_f(__float_as_int(thl[qb * 64 + lane]));
-                G[qb] = fmaxf(G[qb], -0.5f * tg);
-                const float b2 = st[qb * 256 + 64 + lane];
+                const float ta = ord_f(__float_as_int(thl[(QB + qb) * 64 + lane]));
+                const float tb = ord_f(__float_as_int(thl[(2 * QB + qb) * 64 + lane]));
+                G[qb] = fmaxf(G[qb], -0.5f * fminf(tg, fmaxf(ta, tb)));
+                const float b1 = st[qb * 256 + lane], b2 = st[qb * 256 + 64 + lane];
                 if (b2 < tg) atomicMin(const_cast<int*>(gq) + qb * 32 + r, ord_i(b2));
+                if (b1 < (h ? tb : ta)) atomicMin(const_cast<int*>(gq) + (1 + h) * Qpad + qb * 32 + r, ord_i(b1));
             }
         }
         // asynchronous loads: next stage, and the chip-wide thresholds for the next exchange (sc1: from memory)
         if (s + 1 < s_end) stage(s + 1, buf ^ 1);
         if (exchange) {
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-                glds4_sc1(uniform_ptr(gq + qb * 32), (lane_now() & 31) * 4, lds_addr_of(thl) + qb * 256);
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    glds4_sc1(uniform_ptr(gq + a * Qpad + qb * 32), (lane_now() & 31) * 4,
+                              lds_addr_of(thl) + (a * QB + qb) * 256);
         }
         const unsigned lf = lane_now();
         const unsigned frag_off = (lf & 31) * 256u + ((((lf >> 5) ^ lf) & 15) << 4);
@@ -522,7 +534,7 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     if (nChunks < 8) nChunks = 8;
     const int64_t nLists = (int64_t)nChunks * 2;
     const size_t pbytes = (size_t)nLists * Qpad * 8;
-    const size_t gbytes = ((size_t)Qpad * 4 + 255) & ~(size_t)255;
+    const size_t gbytes = ((size_t)Qpad * 12 + 255) & ~(size_t)255;   // three bounds per query
     int rc = imatch_ws_reserve(ctx, 2 * pbytes + gbytes);
     if (rc) return rc;
     float2* pb = (float2*)ctx->ws;
