@@ -199,9 +199,10 @@ extern "C" int imatch_homography(imatch_ctx* ctx, const float* src, const float*
     hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / 256), dim3(256), 0, ctx->stream, (const double*)dev,
                        (const float*)(dev + dbytes), n, seed, (float)(1.0 / (tau * tau)), d_best);
     HIP_TRY(ctx, hipGetLastError());
-    unsigned long long key = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&key, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long* h_key = (unsigned long long*)((char*)ctx->hs + dbytes + fbytes);  // pinned: no staging copy
+    HIP_TRY(ctx, hipMemcpyAsync(h_key, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long key = *h_key;
     if (key == 0) return IMATCH_OK;  // no non-degenerate sample
     const uint32_t h = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
     double Hb[9];

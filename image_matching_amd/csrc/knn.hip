@@ -532,6 +532,7 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     if (nChunks > nStages / 4) nChunks = nStages / 4;
     nChunks = (nChunks / 8) * 8;
     if (nChunks < 8) nChunks = 8;
+    if (const char* e = getenv("IMATCH_KNN_CHUNKS")) nChunks = std::max(8, atoi(e) / 8 * 8);  // tuning override
     const int64_t nLists = (int64_t)nChunks * 2;
     const size_t pbytes = (size_t)nLists * Qpad * 8;
     const size_t gbytes = ((size_t)Qpad * 12 + 255) & ~(size_t)255;   // three bounds per query

@@ -948,14 +948,19 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
     stage_flush_block(stage, n_staged, wcnt, out, cap, count);
 }
 
-// ---- calcSIFTDescriptor: one wavefront per (sorted) keypoint -------------------------------------
+// ---- calcSIFTDescriptor: WPK wavefronts per (sorted) keypoint ------------------------------------
+// The patch samples are spread over 64*WPK lanes (a camera frame has fewer keypoints than the chip has
+// wave slots, so WPK = 4 there: the patch walk is a quarter as long); the 128 outputs are finished by
+// the group's first wave. Fixed-point sums make the result independent of WPK.
 #define DESC_HIST (6 * 6 * 10)
+template <int WPK>
 __global__ void __launch_bounds__(256)
 describe_kernel(PyrTable T, const KpRec* __restrict__ kps, int n_kp, int first_octave, uint8_t* __restrict__ desc) {
-    __shared__ unsigned long long hist[4][DESC_HIST];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int id = blockIdx.x * 4 + wave;
-    for (int i = lane; i < DESC_HIST; i += 64) hist[wave][i] = 0ull;
+    constexpr int GROUPS = 4 / WPK, GL = 64 * WPK;
+    __shared__ unsigned long long hist[GROUPS][DESC_HIST];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x / GL, gl = threadIdx.x % GL;
+    const int id = blockIdx.x * GROUPS + wave;
+    for (int i = gl; i < DESC_HIST; i += GL) hist[wave][i] = 0ull;
     __syncthreads();
     const bool active = id < n_kp;
     const int d = 4, n = 8;
@@ -991,7 +996,7 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, int n_kp, int first_o
         // visiting order does not change a single bit of the result.
         int spread = 1;
         while (spread * 4 <= total) spread <<= 1;
-        for (int q = lane; q < total; q += 64) {
+        for (int q = gl; q < total; q += GL) {
             const int p = (int)(((unsigned)q * (unsigned)spread) % (unsigned)total);
             const int i = p / side - radius, j = p % side - radius;
             const float c_rot = j * cos_t - i * sin_t;
@@ -1029,6 +1034,7 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, int n_kp, int first_o
         }
     }
     __syncthreads();
+    if (gl >= 64) return;  // the group's first wave finishes
     // fold the circular orientation bins, normalise, clamp, renormalise, quantise
     float v[2];
 #pragma unroll
@@ -1449,8 +1455,12 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             // staged in the pinned block (K <= n_kp records fit), which nothing rewrites before the next synchronisation
             memcpy(h_kp, kps.data(), (size_t)K * sizeof(KpRec));
             HIP_TRY(ctx, hipMemcpyAsync(d_sorted, h_kp, (size_t)K * sizeof(KpRec), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(describe_kernel, dim3((K + 3) / 4), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted, K,
-                               first_octave, d_desc);
+            if (K <= 65536)
+                hipLaunchKernelGGL(describe_kernel<4>, dim3(K), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted, K,
+                                   first_octave, d_desc);
+            else
+                hipLaunchKernelGGL(describe_kernel<1>, dim3((K + 3) / 4), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted,
+                                   K, first_octave, d_desc);
             HIP_TRY(ctx, hipGetLastError());
         }
         rc = imatch_features_pack_u8_dev(ctx, f, d_desc);  // bf16 rows + norms, queued (u8 rows are integral by type)

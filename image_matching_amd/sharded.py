@@ -90,9 +90,10 @@ class ShardedMatcher:
             raise ValueError("nq %d exceeds q_cap %d" % (nq, q_cap))
         W = self.world
         if W == 1:
+            # no exchange and no host synchronisation: the result is valid in the backend's stream order
+            # (ratio_dev consumes it there); read it from another stream only after backend.synchronize()
             out = self._buf("dp_out", (q_cap, 4), torch.int32)
             self.backend.knn2_dev(q_features, self.shard, out.data_ptr(), self.offset)
-            self.backend.synchronize()
             return out[:nq]
         qlocal = self._buf("dp_qlocal", (q_cap, 128), torch.uint8)
         qall = self._buf("dp_qall", (W, q_cap, 128), torch.uint8)

@@ -28,3 +28,5 @@ def run(label, **env):
     print("%-28s %.3f ms (min %.3f)  %s" % (label, np.median(ms[1:]), min(ms), "same" if np.array_equal(got, ref) else "DIFFERENT"), flush=True)
 print("Q=%d N=%d" % (nq, len(f_map)))
 run("default")
+for c in (48, 64, 80, 96, 128, 160, 240):
+    run("chunks %d" % c, CHUNKS=c)
