@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--map-side", type=int, default=8192)
     ap.add_argument("--frames", type=int, default=16, help="distinct synthetic frames per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="frames in flight per GPU: each has its own context (stream + arena) and host thread; a step is "
+                         "then one frame per stream")
     args = ap.parse_args()
 
     import torch
@@ -130,42 +133,76 @@ def main():
 
     stats = {"kp": [], "good": [], "found": 0, "knn_ms": [], "pyr_ms": []}
 
-    def step(i, record=False):
-        fr = frames_d[i % len(frames_d)]
-        f = ctx.sift_extract_dev(fr.data_ptr(), 480, 640, 640, params)
+    # extra frames in flight: one context (stream, arena, workspace) and one matcher per stream
+    n_streams = max(1, args.streams)
+    if world > 1 and n_streams > 1:
+        log("note: --streams applies to single-GPU runs (the collectives are issued from one thread); using 1")
+        n_streams = 1
+    ctxs = [ctx] + [im.Context(local_rank) for _ in range(n_streams - 1)]
+    for c in ctxs[1:]:
+        c.set_profiling(True)
+    matchers = [matcher] + [sharded.ShardedMatcher(c, f_shard, lo, dev) for c in ctxs[1:]]
+    import threading
+    stats_lock = threading.Lock()
+
+    def step(i, record=False, lane=0):
+        cx, mt = ctxs[lane], matchers[lane]
+        fr = frames_d[(i * n_streams + lane) % len(frames_d)]
+        f = cx.sift_extract_dev(fr.data_ptr(), 480, 640, 640, params)
         nq = len(f)
-        if record:
-            stats["pyr_ms"].append(ctx.sift_pyramid_ms())
+        pyr_ms = cx.sift_pyramid_ms() if record else 0.0
         if nq > q_cap:
             raise RuntimeError('frame has %d keypoints, exchange buffers hold %d' % (nq, q_cap))
-        out4 = matcher.match_dp(f, nq, q_cap)
-        if record:
-            stats["knn_ms"].append(ctx.knn2_kernel_ms())
-        gq, gt, gd = ctx.ratio_dev(out4.data_ptr(), out4.shape[0], ratio)
+        out4 = mt.match_dp(f, nq, q_cap)
+        gq, gt, gd = cx.ratio_dev(out4.data_ptr(), out4.shape[0], ratio)
+        knn_ms = cx.knn2_kernel_ms() if record else 0.0
         H = None
         if len(gq) > 10:                                   # position_finder.py:316
             kp = f.download(descriptors=False)[0]
-            H, _ = ctx.homography(kp[gq, :2], map_xy[gt], 0.1, seed=i)
+            H, _ = cx.homography(kp[gq, :2], map_xy[gt], 0.1, seed=i)
         f.free()
         if record:
-            stats["kp"].append(nq)
-            stats["good"].append(len(gq))
-            stats["found"] += H is not None
+            with stats_lock:
+                stats["pyr_ms"].append(pyr_ms)
+                stats["knn_ms"].append(knn_ms)
+                stats["kp"].append(nq)
+                stats["good"].append(len(gq))
+                stats["found"] += H is not None
         return H
 
+    def run_steps(n, record):
+        if n_streams == 1:
+            for i in range(n):
+                step(i, record)
+            return
+        errs = []
+
+        def worker(lane):
+            try:
+                for i in range(n):
+                    step(i, record, lane)
+            except Exception as e:      # surfaced after the join
+                errs.append(e)
+        ts = [threading.Thread(target=worker, args=(l,)) for l in range(n_streams)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+
     def barrier():
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(i)
+    run_steps(args.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, record=True)
+    run_steps(args.steps, True)
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
@@ -174,7 +211,7 @@ def main():
         wall = float(tw.item())
 
     if rank == 0:
-        fps = world * args.steps / wall
+        fps = world * n_streams * args.steps / wall
         q_mean = float(np.mean(stats["kp"]))
         knn_ms = float(np.mean(stats["knn_ms"]))
         n_local = hi - lo
@@ -192,6 +229,7 @@ def main():
                        "frame": "640x480 u8", "map_descriptors": n_map, "keypoints_per_frame": q_mean,
                        "good_matches_per_frame": float(np.mean(stats["good"])),
                        "homographies_found": "%d/%d" % (stats["found"], args.steps), "ratio": ratio,
+                       "frames_in_flight_per_gpu": n_streams,
                        "parallelism": "map sharded x%d, frames data-parallel" % world if world > 1 else "single GPU"},
             "knn_gdist_per_s": world * q_mean * n_map / (knn_ms * 1e-3) / 1e9 if world == 1
                                else world * q_cap * float(n_local) * world / (knn_ms * 1e-3) / 1e9,

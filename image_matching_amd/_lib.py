@@ -59,6 +59,14 @@ SIGNATURES = {
                                            ctypes.POINTER(SiftParams), ctypes.POINTER(c_vp)]),
     "imatch_sift_extract_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.POINTER(SiftParams), ctypes.POINTER(c_vp)]),
+    "imatch_sift_extract_batch_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_int, ctypes.POINTER(SiftParams), ctypes.POINTER(c_vp),
+                                                     ctypes.POINTER(c_i64)]),
+    "imatch_ratio_batch_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_i64), ctypes.c_int, ctypes.c_double, c_i32p,
+                                              c_i32p, c_f32p, ctypes.POINTER(c_i64)]),
+    "imatch_homography_batch": (ctypes.c_int, [c_vp, c_f32p, c_f32p, ctypes.POINTER(c_i64), ctypes.c_int, ctypes.c_double,
+                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), c_u8p,
+                                               ctypes.POINTER(ctypes.c_int)]),
     "imatch_features_desc_u8_dev": (ctypes.c_int, [c_vp, c_vp]),
     "imatch_features_download": (ctypes.c_int, [c_vp, c_f32p, c_f32p]),
     "imatch_features_image": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int]),
@@ -284,6 +292,19 @@ class Context:
             n = self.lib.imatch_features_count(hnd)
         return Features(self, hnd, n)
 
+    def sift_extract_batch_dev(self, img_ptr, n_img, img_pitch, h, w, stride=None, params=None):
+        """SIFT on n_img equally sized u8 images in device memory (image b at img_ptr + b*img_pitch bytes), every
+        kernel launched once for the batch. -> (Features holding all rows, offsets int64 [n_img+1])."""
+        params = params or SiftParams()
+        hnd = c_vp()
+        offs = np.zeros(int(n_img) + 1, np.int64)
+        with self.lock:
+            self._check(self.lib.imatch_sift_extract_batch_dev(
+                self._h, c_vp(img_ptr), int(n_img), int(img_pitch), int(h), int(w), int(stride if stride is not None else w),
+                ctypes.byref(params), ctypes.byref(hnd), offs.ctypes.data_as(ctypes.POINTER(c_i64))))
+            n = self.lib.imatch_features_count(hnd)
+        return Features(self, hnd, n), offs
+
     def sift_debug_layer(self, kind, o, i):
         r, c = ctypes.c_int(), ctypes.c_int()
         with self.lock:
@@ -317,6 +338,26 @@ class Context:
             return None, None
         return H, mask[:n]
 
+    def homography_batch(self, src, dst, offsets, thr=0.1, seeds=None):
+        """len(offsets)-1 independent findHomography problems in one launch: problem b is rows
+        offsets[b]..offsets[b+1] of src/dst. -> (H float64 [n,3,3], mask uint8 [total], found bool [n])."""
+        src = np.ascontiguousarray(np.asarray(src, dtype=np.float32).reshape(-1, 2))
+        dst = np.ascontiguousarray(np.asarray(dst, dtype=np.float32).reshape(-1, 2))
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        n_seg = len(offs) - 1
+        if src.shape != dst.shape or src.shape[0] != int(offs[-1]):
+            raise ValueError("src, dst and offsets disagree")
+        sd = np.ascontiguousarray(seeds if seeds is not None else np.zeros(n_seg), dtype=np.uint64)
+        H = np.zeros((n_seg, 3, 3), np.float64)
+        mask = np.zeros(max(src.shape[0], 1), np.uint8)
+        found = np.zeros(n_seg, np.int32)
+        with self.lock:
+            self._check(self.lib.imatch_homography_batch(
+                self._h, _ptr(src, c_f32p), _ptr(dst, c_f32p), offs.ctypes.data_as(ctypes.POINTER(c_i64)), n_seg, float(thr),
+                sd.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), H.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                _ptr(mask, c_u8p), found.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return H, mask[:src.shape[0]], found.astype(bool)
+
     # -- kNN ---------------------------------------------------------------------------
     def knn2(self, q, t):
         """-> (idx int32 [Q,2], dist f32 [Q,2]); missing neighbours are (-1, inf)."""
@@ -344,3 +385,19 @@ class Context:
                                                   _ptr(gt, c_i32p), _ptr(gd, c_f32p), ctypes.byref(n)))
         g = n.value
         return gq[:g].copy(), gt[:g].copy(), gd[:g].copy()
+
+    def ratio_batch_dev(self, out4_ptr, offsets, ratio):
+        """Ratio test on the rows of a batch: -> (good_q local to each segment, good_t, good_d, good_offsets)."""
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        n_seg = len(offs) - 1
+        nq = int(offs[-1])
+        gq = np.empty(max(nq, 1), np.int32)
+        gt = np.empty(max(nq, 1), np.int32)
+        gd = np.empty(max(nq, 1), np.float32)
+        goff = np.zeros(n_seg + 1, np.int64)
+        with self.lock:
+            self._check(self.lib.imatch_ratio_batch_dev(self._h, c_vp(out4_ptr), offs.ctypes.data_as(ctypes.POINTER(c_i64)),
+                                                        n_seg, float(ratio), _ptr(gq, c_i32p), _ptr(gt, c_i32p),
+                                                        _ptr(gd, c_f32p), goff.ctypes.data_as(ctypes.POINTER(c_i64))))
+        g = int(goff[-1])
+        return gq[:g].copy(), gt[:g].copy(), gd[:g].copy(), goff

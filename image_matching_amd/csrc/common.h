@@ -50,8 +50,15 @@ struct imatch_features {
 
 #define IMATCH_ROW_PAD 1024
 
+// Batched extraction: rows [off[b], off[b+1]) of a concatenated set belong to image b.
+#define IMATCH_MAX_BATCH 64
+struct imatch_segtab { int n; int off[IMATCH_MAX_BATCH + 1]; };
+
 int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out);
 int imatch_features_pack_u8_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev);
+// rows of image b are read from src_dev + b*zs (bytes) + (row - off[b])*128
+int imatch_features_pack_u8_seg_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev, const imatch_segtab* seg,
+                                    size_t zs);
 void imatch_sift_state_free(imatch_ctx* ctx);
 int imatch_set_err(imatch_ctx* ctx, int code, const char* fmt, ...);
 int imatch_ws_reserve(imatch_ctx* ctx, size_t bytes);

@@ -77,9 +77,26 @@ __host__ __device__ static inline bool hypothesis(const double* pts, int n, uint
     return true;
 }
 
+// grid (HOMO_HYPOTHESES / 256, segments): segment b (= image b of a batch; a single call is one
+// segment) holds n_b = off[b+1] - off[b] correspondences, its normalised points at pts + 4 * off[b]
+// doubles ([4][n_b]: sx, sy, dx, dy) and fpts + 4 * off[b] floats, its MSAC scale in inv_tau2[b] and
+// its sampler seed in seeds[b].
+struct HomoSeg {
+    imatch_segtab seg;
+    float inv_tau2[IMATCH_MAX_BATCH];
+    unsigned long long seeds[IMATCH_MAX_BATCH];
+};
+
 __global__ void __launch_bounds__(256)
-homography_score_kernel(const double* __restrict__ pts, const float* __restrict__ fpts, int n, uint64_t seed,
-                        float inv_tau2, unsigned long long* __restrict__ best) {
+homography_score_kernel(const double* __restrict__ pts_all, const float* __restrict__ fpts_all, HomoSeg hs,
+                        unsigned long long* __restrict__ best) {
+    const int b = blockIdx.y;
+    const int n = hs.seg.off[b + 1] - hs.seg.off[b];
+    if (n < 4) return;
+    const double* pts = pts_all + 4 * (size_t)hs.seg.off[b];
+    const float* fpts = fpts_all + 4 * (size_t)hs.seg.off[b];
+    const uint64_t seed = hs.seeds[b];
+    const float inv_tau2 = hs.inv_tau2[b];
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
     if (h >= HOMO_HYPOTHESES) return;
     double H[9];
@@ -99,7 +116,7 @@ homography_score_kernel(const double* __restrict__ pts, const float* __restrict_
     }
     // scores are >= 0: their bit patterns order like the floats; ties go to the lower h
     const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (0xFFFFFFFFu - h);
-    atomicMax(best, key);
+    atomicMax(best + b, key);
 }
 
 static void hartley(const float* p, int n, double T[3]) {
@@ -169,63 +186,120 @@ static bool refit(const double* P, int n, double tau2, double h8[8]) {
     return true;
 }
 
-extern "C" int imatch_homography(imatch_ctx* ctx, const float* src, const float* dst, int n, double thr, uint64_t seed,
-                                 double* H_out, uint8_t* mask, int* found) {
-    if (!ctx || !found || !H_out || n < 0 || (n > 0 && (!src || !dst))) return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
-    *found = 0;
-    if (mask && n > 0) memset(mask, 0, (size_t)n);
-    if (n < 4) return IMATCH_OK;  // cv2.findHomography returns (None, None)
+// Shared by the single and the batched entry point: segment b's correspondences are src/dst rows
+// [off[b], off[b+1]).
+static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, const imatch_segtab& seg, double thr,
+                          const uint64_t* seeds, double* H_out /* [n_seg][9] */, uint8_t* mask, int* found) {
+    const int nseg = seg.n;
+    const int64_t ntot = seg.off[nseg];
+    for (int b = 0; b < nseg; ++b) found[b] = 0;
+    if (mask && ntot > 0) memset(mask, 0, (size_t)ntot);
+    bool any = false;
+    for (int b = 0; b < nseg; ++b) any = any || seg.off[b + 1] - seg.off[b] >= 4;
+    if (!any) return IMATCH_OK;  // cv2.findHomography returns (None, None)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    double Ts[3], Td[3];
-    hartley(src, n, Ts);
-    hartley(dst, n, Td);
-    const size_t dbytes = sizeof(double) * 4 * (size_t)n, fbytes = sizeof(float) * 4 * (size_t)n;
-    int rc = imatch_hs_reserve(ctx, dbytes + fbytes + 64);
+    const size_t dbytes = sizeof(double) * 4 * (size_t)ntot, fbytes = sizeof(float) * 4 * (size_t)ntot;
+    const size_t kbytes = 8 * (size_t)nseg;
+    int rc = imatch_hs_reserve(ctx, dbytes + fbytes + kbytes + 64);
     if (rc) return rc;
-    rc = imatch_ws_reserve(ctx, dbytes + fbytes + 256);
+    rc = imatch_ws_reserve(ctx, dbytes + fbytes + kbytes + 256);
     if (rc) return rc;
-    double* P = (double*)ctx->hs;
-    float* F = (float*)((char*)ctx->hs + dbytes);
-    for (int i = 0; i < n; ++i) {
-        P[i] = Ts[0] * (src[2 * i] - Ts[1]); P[n + i] = Ts[0] * (src[2 * i + 1] - Ts[2]);
-        P[2 * n + i] = Td[0] * (dst[2 * i] - Td[1]); P[3 * n + i] = Td[0] * (dst[2 * i + 1] - Td[2]);
+    double* Pall = (double*)ctx->hs;
+    float* Fall = (float*)((char*)ctx->hs + dbytes);
+    HomoSeg hs;
+    memset(&hs, 0, sizeof(hs));
+    hs.seg = seg;
+    std::vector<double> Ts(3 * (size_t)nseg), Td(3 * (size_t)nseg), tau((size_t)nseg, 0.0);
+    for (int b = 0; b < nseg; ++b) {
+        const int n = seg.off[b + 1] - seg.off[b];
+        hs.seeds[b] = seeds[b];
+        if (n < 4) continue;
+        const float* sp = src + 2 * (size_t)seg.off[b];
+        const float* dp = dst + 2 * (size_t)seg.off[b];
+        double* ts = &Ts[3 * b];
+        double* td = &Td[3 * b];
+        hartley(sp, n, ts);
+        hartley(dp, n, td);
+        double* P = Pall + 4 * (size_t)seg.off[b];
+        float* F = Fall + 4 * (size_t)seg.off[b];
+        for (int i = 0; i < n; ++i) {
+            P[i] = ts[0] * (sp[2 * i] - ts[1]); P[n + i] = ts[0] * (sp[2 * i + 1] - ts[2]);
+            P[2 * n + i] = td[0] * (dp[2 * i] - td[1]); P[3 * n + i] = td[0] * (dp[2 * i + 1] - td[2]);
+        }
+        for (int i = 0; i < 4 * n; ++i) F[i] = (float)P[i];
+        tau[b] = fmax(thr, HOMO_TAU_FLOOR) * td[0];
+        hs.inv_tau2[b] = (float)(1.0 / (tau[b] * tau[b]));
     }
-    for (int i = 0; i < 4 * n; ++i) F[i] = (float)P[i];
     char* dev = (char*)ctx->ws;
     unsigned long long* d_best = (unsigned long long*)(dev + dbytes + fbytes);
     HIP_TRY(ctx, hipMemcpyAsync(dev, ctx->hs, dbytes + fbytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(d_best, 0, 8, ctx->stream));
-    const double tau = fmax(thr, HOMO_TAU_FLOOR) * Td[0];
-    hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / 256), dim3(256), 0, ctx->stream, (const double*)dev,
-                       (const float*)(dev + dbytes), n, seed, (float)(1.0 / (tau * tau)), d_best);
+    HIP_TRY(ctx, hipMemsetAsync(d_best, 0, kbytes, ctx->stream));
+    hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / 256, nseg), dim3(256), 0, ctx->stream,
+                       (const double*)dev, (const float*)(dev + dbytes), hs, d_best);
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long* h_key = (unsigned long long*)((char*)ctx->hs + dbytes + fbytes);  // pinned: no staging copy
-    HIP_TRY(ctx, hipMemcpyAsync(h_key, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h_key, d_best, kbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const unsigned long long key = *h_key;
-    if (key == 0) return IMATCH_OK;  // no non-degenerate sample
-    const uint32_t h = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
-    double Hb[9];
-    if (!hypothesis(P, n, seed, h, Hb) || fabs(Hb[8]) <= 1e-9) return IMATCH_OK;
-    double h8[8];
-    for (int k = 0; k < 8; ++k) h8[k] = Hb[k] / Hb[8];
-    if (!refit(P, n, tau * tau, h8)) return IMATCH_OK;
-    const double Hn[9] = {h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7], 1.0};
-    const double TS[9] = {Ts[0], 0, -Ts[0] * Ts[1], 0, Ts[0], -Ts[0] * Ts[2], 0, 0, 1};
-    const double TDi[9] = {1.0 / Td[0], 0, Td[1], 0, 1.0 / Td[0], Td[2], 0, 0, 1};
-    double t[9], H[9];
-    mul3(Hn, TS, t);
-    mul3(TDi, t, H);
-    if (fabs(H[8]) < 1e-12) return IMATCH_OK;
-    for (int k = 0; k < 9; ++k) H_out[k] = H[k] / H[8];
-    if (mask)
-        for (int i = 0; i < n; ++i) {
-            const double x = src[2 * i], y = src[2 * i + 1];
-            const double ww = H_out[6] * x + H_out[7] * y + 1.0;
-            const double ex = (H_out[0] * x + H_out[1] * y + H_out[2]) / ww - dst[2 * i];
-            const double ey = (H_out[3] * x + H_out[4] * y + H_out[5]) / ww - dst[2 * i + 1];
-            mask[i] = (ex * ex + ey * ey <= thr * thr) ? 1 : 0;
-        }
-    *found = 1;
+    for (int b = 0; b < nseg; ++b) {
+        const int n = seg.off[b + 1] - seg.off[b];
+        const unsigned long long key = h_key[b];
+        if (n < 4 || key == 0) continue;  // no non-degenerate sample
+        const double* P = Pall + 4 * (size_t)seg.off[b];
+        const float* sp = src + 2 * (size_t)seg.off[b];
+        const float* dp = dst + 2 * (size_t)seg.off[b];
+        const double* ts = &Ts[3 * b];
+        const double* td = &Td[3 * b];
+        const uint32_t h = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+        double Hb[9];
+        if (!hypothesis(P, n, seeds[b], h, Hb) || fabs(Hb[8]) <= 1e-9) continue;
+        double h8[8];
+        for (int k = 0; k < 8; ++k) h8[k] = Hb[k] / Hb[8];
+        if (!refit(P, n, tau[b] * tau[b], h8)) continue;
+        const double Hn[9] = {h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7], 1.0};
+        const double TS[9] = {ts[0], 0, -ts[0] * ts[1], 0, ts[0], -ts[0] * ts[2], 0, 0, 1};
+        const double TDi[9] = {1.0 / td[0], 0, td[1], 0, 1.0 / td[0], td[2], 0, 0, 1};
+        double t[9], H[9];
+        mul3(Hn, TS, t);
+        mul3(TDi, t, H);
+        if (fabs(H[8]) < 1e-12) continue;
+        double* Ho = H_out + 9 * (size_t)b;
+        for (int k = 0; k < 9; ++k) Ho[k] = H[k] / H[8];
+        if (mask)
+            for (int i = 0; i < n; ++i) {
+                const double x = sp[2 * i], y = sp[2 * i + 1];
+                const double ww = Ho[6] * x + Ho[7] * y + 1.0;
+                const double ex = (Ho[0] * x + Ho[1] * y + Ho[2]) / ww - dp[2 * i];
+                const double ey = (Ho[3] * x + Ho[4] * y + Ho[5]) / ww - dp[2 * i + 1];
+                mask[seg.off[b] + i] = (ex * ex + ey * ey <= thr * thr) ? 1 : 0;
+            }
+        found[b] = 1;
+    }
     return IMATCH_OK;
+}
+
+extern "C" int imatch_homography(imatch_ctx* ctx, const float* src, const float* dst, int n, double thr, uint64_t seed,
+                                 double* H_out, uint8_t* mask, int* found) {
+    if (!ctx || !found || !H_out || n < 0 || (n > 0 && (!src || !dst))) return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    imatch_segtab seg;
+    memset(&seg, 0, sizeof(seg));
+    seg.n = 1;
+    seg.off[1] = n;
+    return homography_run(ctx, src, dst, seg, thr, &seed, H_out, mask, found);
+}
+
+extern "C" int imatch_homography_batch(imatch_ctx* ctx, const float* src, const float* dst, const int64_t* offsets,
+                                       int n_seg, double thr, const uint64_t* seeds, double* H_out, uint8_t* mask,
+                                       int* found) {
+    if (!ctx || !found || !H_out || !offsets || !seeds || n_seg < 1 || n_seg > IMATCH_MAX_BATCH)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    imatch_segtab seg;
+    memset(&seg, 0, sizeof(seg));
+    seg.n = n_seg;
+    for (int b = 0; b <= n_seg; ++b) {
+        if (offsets[b] < 0 || offsets[b] > INT_MAX / 8 || (b > 0 && offsets[b] < offsets[b - 1]) || (b == 0 && offsets[0] != 0))
+            return imatch_set_err(ctx, IMATCH_EINVAL, "segment offsets must start at 0 and ascend");
+        seg.off[b] = (int)offsets[b];
+    }
+    if (seg.off[n_seg] > 0 && (!src || !dst)) return imatch_set_err(ctx, IMATCH_EINVAL, "null points");
+    return homography_run(ctx, src, dst, seg, thr, seeds, H_out, mask, found);
 }

@@ -353,20 +353,23 @@ __global__ void merge_top2_kernel(const int4* __restrict__ in, int nLists, int64
 // Lowe ratio test with the reference's float semantics (match_finder.py:193): the f32-rounded
 // distances are widened to double, the product is a double. Survivors are compacted in query
 // order by one workgroup (a block-wide exclusive scan per 1024 queries).
+// One workgroup per segment (= per image of a batch; a single call is one segment): survivors of
+// queries [off[b], off[b+1]) are written from position off[b] on, with query indices local to the segment.
 __global__ void __launch_bounds__(1024)
-ratio_kernel(const int4* __restrict__ in, int64_t nq, double ratio, int* __restrict__ gq, int* __restrict__ gt,
+ratio_kernel(const int4* __restrict__ in, imatch_segtab seg, double ratio, int* __restrict__ gq, int* __restrict__ gt,
              float* __restrict__ gd, unsigned long long* __restrict__ n_good) {
     __shared__ int wsum[16];
     __shared__ int base_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q_lo = seg.off[blockIdx.x], q_hi = seg.off[blockIdx.x + 1];
     if (threadIdx.x == 0) base_s = 0;
     __syncthreads();
-    for (int64_t q0 = 0; q0 < nq; q0 += 1024) {
+    for (int64_t q0 = q_lo; q0 < q_hi; q0 += 1024) {
         const int64_t q = q0 + threadIdx.x;
         bool good = false;
         int4 e = make_int4(0, -1, 0, -1);
         float d1 = 0.f;
-        if (q < nq) {
+        if (q < q_hi) {
             e = in[q];
             if (e.y >= 0 && e.w >= 0) {
                 d1 = sqrtf((float)e.x);
@@ -378,10 +381,10 @@ ratio_kernel(const int4* __restrict__ in, int64_t nq, double ratio, int* __restr
         const int within = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) wsum[wave] = __popcll(m);
         __syncthreads();
-        int off = base_s;
+        int64_t off = q_lo + base_s;
         for (int w = 0; w < wave; ++w) off += wsum[w];
         if (good) {
-            gq[off + within] = (int)q;
+            gq[off + within] = (int)(q - q_lo);
             gt[off + within] = e.y;
             gd[off + within] = d1;
         }
@@ -393,22 +396,29 @@ ratio_kernel(const int4* __restrict__ in, int64_t nq, double ratio, int* __restr
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_good = (unsigned long long)base_s;
+    if (threadIdx.x == 0) n_good[blockIdx.x] = (unsigned long long)base_s;
 }
 
 // ---- descriptor upload: u8 / f32 -> bf16 rows + squared norms ------------------------------
 // one wave per row; lane handles 2 values
-template <typename T>
+template <typename T, bool SEG = false>
 __global__ void pack_rows_kernel(const T* __restrict__ src, int64_t n, int64_t n_pad, uint16_t* __restrict__ dst,
-                                 float* __restrict__ norm, float* __restrict__ hneg, int* __restrict__ flag) {
+                                 float* __restrict__ norm, float* __restrict__ hneg, int* __restrict__ flag,
+                                 imatch_segtab seg = imatch_segtab(), size_t zs = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n_pad) return;
     float a = 0.f, b = 0.f;
     bool bad = false;
     if (row < n) {
-        a = (float)src[row * 128 + 2 * lane];
-        b = (float)src[row * 128 + 2 * lane + 1];
+        const T* s = src + row * 128;
+        if (SEG) {  // the row's image (wave-uniform scan of at most IMATCH_MAX_BATCH offsets)
+            int im = 0;
+            while (im + 1 < seg.n && row >= seg.off[im + 1]) ++im;
+            s = (const T*)((const char*)src + (size_t)im * zs) + (row - seg.off[im]) * 128;
+        }
+        a = (float)s[2 * lane];
+        b = (float)s[2 * lane + 1];
         bad = !(a >= 0.f && a <= 255.f && a == truncf(a)) || !(b >= 0.f && b <= 255.f && b == truncf(b));
     }
     const __bf16 ha = (__bf16)a, hb = (__bf16)b;
@@ -442,6 +452,17 @@ int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out) {
     f->flag = (int*)((char*)f->desc + (size_t)f->n_pad * (256 + 8));
     f->hneg = f->norm + f->n_pad;
     *out = f;
+    return IMATCH_OK;
+}
+
+int imatch_features_pack_u8_seg_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev, const imatch_segtab* seg,
+                                    size_t zs) {
+    HIP_TRY(ctx, hipMemsetAsync(f->flag, 0, 256, ctx->stream));
+    const unsigned grid = (unsigned)((f->n_pad + 3) / 4);
+    hipLaunchKernelGGL((pack_rows_kernel<uint8_t, true>), dim3(grid), dim3(256), 0, ctx->stream, src_dev, f->n, f->n_pad,
+                       f->desc, f->norm, f->hneg, f->flag, *seg, zs);
+    HIP_TRY(ctx, hipGetLastError());
+    f->integral = 1;
     return IMATCH_OK;
 }
 
@@ -646,33 +667,72 @@ int imatch_merge_top2_dev(imatch_ctx* ctx, const int32_t* in4_dev, int n_lists, 
     return IMATCH_OK;
 }
 
-int imatch_ratio_dev(imatch_ctx* ctx, const int32_t* out4_dev, int64_t nq, double ratio, int32_t* good_q,
-                     int32_t* good_t, float* good_d, int64_t* n_good) {
-    if (!ctx || !n_good || nq < 0 || (nq > 0 && (!out4_dev || !good_q || !good_t || !good_d)))
-        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
-    *n_good = 0;
-    if (nq == 0) return IMATCH_OK;
+static int ratio_run(imatch_ctx* ctx, const int32_t* out4_dev, const imatch_segtab& seg, double ratio, int32_t* good_q,
+                     int32_t* good_t, float* good_d, int64_t* good_off) {
+    const int64_t nq = seg.off[seg.n];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // workspace: gq, gt, gd (nq each) + counter; placed after any knn partials are consumed (same stream)
+    // gq, gt, gd (nq each) + one counter per segment
     const size_t arr = ((size_t)nq * 4 + 255) & ~(size_t)255;
-    char* dev = (char*)imatch_pool_alloc(ctx, 3 * arr + 256);
+    const size_t cnt = ((size_t)seg.n * 8 + 255) & ~(size_t)255;
+    char* dev = (char*)imatch_pool_alloc(ctx, 3 * arr + cnt);
     if (!dev) return imatch_set_err(ctx, IMATCH_ENOMEM, "match lists for %lld queries", (long long)nq);
-    int rc = imatch_hs_reserve(ctx, 3 * arr + 256);
+    int rc = imatch_hs_reserve(ctx, 3 * arr + cnt);
     if (rc) { imatch_pool_free(ctx, dev); return rc; }
-    hipLaunchKernelGGL(ratio_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int4*)out4_dev, nq, ratio, (int*)dev,
+    hipLaunchKernelGGL(ratio_kernel, dim3(seg.n), dim3(1024), 0, ctx->stream, (const int4*)out4_dev, seg, ratio, (int*)dev,
                        (int*)(dev + arr), (float*)(dev + 2 * arr), (unsigned long long*)(dev + 3 * arr));
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->hs, dev, 3 * arr + 256, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->hs, dev, 3 * arr + cnt, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     imatch_pool_free(ctx, dev);
     if (e != hipSuccess) return imatch_set_err(ctx, IMATCH_EHIP, "ratio: %s", hipGetErrorString(e));
     const char* hsrc = (const char*)ctx->hs;
-    const int64_t g = (int64_t)*(const unsigned long long*)(hsrc + 3 * arr);
-    memcpy(good_q, hsrc, (size_t)g * 4);
-    memcpy(good_t, hsrc + arr, (size_t)g * 4);
-    memcpy(good_d, hsrc + 2 * arr, (size_t)g * 4);
-    *n_good = g;
+    const unsigned long long* ng = (const unsigned long long*)(hsrc + 3 * arr);
+    int64_t at = 0;
+    for (int b = 0; b < seg.n; ++b) {
+        const int64_t g = (int64_t)ng[b], lo = seg.off[b];
+        good_off[b] = at;
+        memcpy(good_q + at, hsrc + lo * 4, (size_t)g * 4);
+        memcpy(good_t + at, hsrc + arr + lo * 4, (size_t)g * 4);
+        memcpy(good_d + at, hsrc + 2 * arr + lo * 4, (size_t)g * 4);
+        at += g;
+    }
+    good_off[seg.n] = at;
     return IMATCH_OK;
+}
+
+int imatch_ratio_dev(imatch_ctx* ctx, const int32_t* out4_dev, int64_t nq, double ratio, int32_t* good_q,
+                     int32_t* good_t, float* good_d, int64_t* n_good) {
+    if (!ctx || !n_good || nq < 0 || nq > INT_MAX || (nq > 0 && (!out4_dev || !good_q || !good_t || !good_d)))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    *n_good = 0;
+    if (nq == 0) return IMATCH_OK;
+    imatch_segtab seg;
+    memset(&seg, 0, sizeof(seg));
+    seg.n = 1;
+    seg.off[1] = (int)nq;
+    int64_t off[2] = {0, 0};
+    int rc = ratio_run(ctx, out4_dev, seg, ratio, good_q, good_t, good_d, off);
+    if (rc) return rc;
+    *n_good = off[1];
+    return IMATCH_OK;
+}
+
+int imatch_ratio_batch_dev(imatch_ctx* ctx, const int32_t* out4_dev, const int64_t* offsets, int n_seg, double ratio,
+                           int32_t* good_q, int32_t* good_t, float* good_d, int64_t* good_offsets) {
+    if (!ctx || !offsets || !good_offsets || n_seg < 1 || n_seg > IMATCH_MAX_BATCH)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    imatch_segtab seg;
+    memset(&seg, 0, sizeof(seg));
+    seg.n = n_seg;
+    for (int b = 0; b <= n_seg; ++b) {
+        if (offsets[b] < 0 || offsets[b] > INT_MAX || (b > 0 && offsets[b] < offsets[b - 1]))
+            return imatch_set_err(ctx, IMATCH_EINVAL, "segment offsets must ascend");
+        seg.off[b] = (int)offsets[b];
+    }
+    for (int b = 0; b <= n_seg; ++b) good_offsets[b] = 0;
+    if (seg.off[n_seg] == 0) return IMATCH_OK;
+    if (offsets[0] != 0 || !out4_dev || !good_q || !good_t || !good_d) return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    return ratio_run(ctx, out4_dev, seg, ratio, good_q, good_t, good_d, good_offsets);
 }
 
 }  // extern "C"

@@ -21,7 +21,10 @@ __device__ __forceinline__ uint8_t sat_u8(float v) {
 // grid (tiles_x*tiles_y, slices): each block histograms a band of rows of one tile
 __global__ void __launch_bounds__(256)
 clahe_hist_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, int tw, int th, int tiles_x,
-                  int* __restrict__ hist) {
+                  int* __restrict__ hist, size_t src_zs, size_t zs) {
+    // batched: image blockIdx.z, its source src_zs bytes and its scratch / output zs bytes further on
+    src += (size_t)blockIdx.z * src_zs;
+    hist = (int*)((char*)hist + (size_t)blockIdx.z * zs);
     __shared__ int h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -38,7 +41,9 @@ clahe_hist_kernel(const uint8_t* __restrict__ src, int rows, int cols, int strid
 
 // one block per tile: clip, redistribute, cumulative sum -> LUT
 __global__ void __launch_bounds__(256)
-clahe_lut_kernel(const int* __restrict__ hist, int clip, float lut_scale, uint8_t* __restrict__ lut) {
+clahe_lut_kernel(const int* __restrict__ hist, int clip, float lut_scale, uint8_t* __restrict__ lut, size_t zs) {
+    hist = (const int*)((const char*)hist + (size_t)blockIdx.z * zs);
+    lut += (size_t)blockIdx.z * zs;
     __shared__ int s[256];
     __shared__ int total;
     const int i = threadIdx.x;
@@ -73,7 +78,10 @@ clahe_lut_kernel(const int* __restrict__ hist, int clip, float lut_scale, uint8_
 
 __global__ void __launch_bounds__(256)
 clahe_apply_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, int tw, int th, int tiles_x,
-                   int tiles_y, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst) {
+                   int tiles_y, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst, size_t src_zs, size_t zs) {
+    src += (size_t)blockIdx.z * src_zs;
+    lut += (size_t)blockIdx.z * zs;
+    dst += (size_t)blockIdx.z * zs;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
@@ -96,7 +104,8 @@ clahe_apply_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stri
 }
 
 int imatch_clahe_dev(imatch_ctx* ctx, const uint8_t* src_dev, int h, int w, int stride, double clip_limit, int tiles_x,
-                     int tiles_y, uint8_t* dst_dev, void* scratch /* >= tiles*(1024+256) bytes */) {
+                     int tiles_y, uint8_t* dst_dev, void* scratch /* >= tiles*(1024+256) bytes */, int batch, size_t src_zs,
+                     size_t zs) {
     int eh = h, ew = w;
     if (w % tiles_x != 0 || h % tiles_y != 0) {
         eh = h + (tiles_y - h % tiles_y);
@@ -111,14 +120,16 @@ int imatch_clahe_dev(imatch_ctx* ctx, const uint8_t* src_dev, int h, int w, int 
     }
     int* hist = (int*)scratch;
     uint8_t* lut = (uint8_t*)scratch + (size_t)tiles * 1024;
-    HIP_TRY(ctx, hipMemsetAsync(hist, 0, (size_t)tiles * 1024, ctx->stream));
+    if (batch == 1) HIP_TRY(ctx, hipMemsetAsync(hist, 0, (size_t)tiles * 1024, ctx->stream));
+    else HIP_TRY(ctx, hipMemset2DAsync(hist, zs, 0, (size_t)tiles * 1024, (size_t)batch, ctx->stream));
     int slices = (th + 63) / 64;
     if (slices > 64) slices = 64;
-    hipLaunchKernelGGL(clahe_hist_kernel, dim3(tiles, slices), dim3(256), 0, ctx->stream, src_dev, h, w, stride, tw, th,
-                       tiles_x, hist);
-    hipLaunchKernelGGL(clahe_lut_kernel, dim3(tiles), dim3(256), 0, ctx->stream, hist, clip, (float)255 / total, lut);
-    hipLaunchKernelGGL(clahe_apply_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, ctx->stream, src_dev, h, w,
-                       stride, tw, th, tiles_x, tiles_y, lut, dst_dev);
+    hipLaunchKernelGGL(clahe_hist_kernel, dim3(tiles, slices, batch), dim3(256), 0, ctx->stream, src_dev, h, w, stride, tw,
+                       th, tiles_x, hist, src_zs, zs);
+    hipLaunchKernelGGL(clahe_lut_kernel, dim3(tiles, 1, batch), dim3(256), 0, ctx->stream, hist, clip, (float)255 / total, lut,
+                       zs);
+    hipLaunchKernelGGL(clahe_apply_kernel, dim3((w + 63) / 64, (h + 3) / 4, batch), dim3(256), 0, ctx->stream, src_dev, h, w,
+                       stride, tw, th, tiles_x, tiles_y, lut, dst_dev, src_zs, zs);
     HIP_TRY(ctx, hipGetLastError());
     return IMATCH_OK;
 }

@@ -40,6 +40,13 @@ struct PyrTable {
     int n_oct, nl;
 };
 
+// Batched extraction: image b of a batch lives in the same arena layout shifted by b * zs bytes, and
+// every kernel is launched with gridDim.z = batch size. ZP shifts a frame-0 pointer to this block's frame.
+#define ZP(p) ((decltype(p))((char*)(p) + zo))
+#define TG(o, i) ((float*)((char*)T.gauss[o][i] + zo))
+#define TD(o, i) ((float*)((char*)T.dog[o][i] + zo))
+typedef imatch_segtab SegTab;   // rows of image b: [off[b], off[b+1])
+
 struct RefinedKp {   // output of refine, input of orient
     float x, y, size, response;
     int octave;      // packed: o + (layer << 8) + (cvRound((xi+0.5)*255) << 16)
@@ -87,7 +94,10 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 // ---- createInitialImage: u8 -> f32, x2 INTER_LINEAR ------------------------------------------
 __global__ void __launch_bounds__(256)
-upsample2_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, float* __restrict__ dst) {
+upsample2_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, float* __restrict__ dst, size_t src_zs,
+                 size_t zs) {
+    src += (size_t)blockIdx.z * src_zs;
+    dst = (float*)((char*)dst + (size_t)blockIdx.z * zs);
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= 2 * cols || dy >= 2 * rows) return;
@@ -130,7 +140,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int R>
 __global__ void __launch_bounds__(256, 4)
-blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int rows, int cols, GK<R> gk) {
+blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int rows, int cols, GK<R> gk,
+            size_t zs) {
+    {
+        const size_t zo = (size_t)blockIdx.z * zs;
+        src = ZP(src); dst = ZP(dst);
+        if (dog) dog = ZP(dog);
+    }
     constexpr int N = 2 * R + 1, TH = 32, H2 = TH + 2 * R;      // H2 is even
     constexpr int XO = (R + 3) & ~3, P = 64 + 2 * XO;            // x origin of the tile = x0 - XO; P % 8 == 0
     constexpr int NX4 = P / 4, NITEM = (H2 / 2) * NX4;           // one item = 4 columns of a row pair
@@ -253,7 +269,9 @@ blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __res
 struct GKrt { int r; float k[2 * RT_MAXR + 1]; };
 
 __global__ void __launch_bounds__(256)
-blur_rows_rt_kernel(const float* __restrict__ src, float* __restrict__ tmp, int rows, int cols, GKrt gk) {
+blur_rows_rt_kernel(const float* __restrict__ src, float* __restrict__ tmp, int rows, int cols, GKrt gk, size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    src = ZP(src); tmp = ZP(tmp);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
     const float* s = src + (size_t)y * cols;
@@ -264,7 +282,10 @@ blur_rows_rt_kernel(const float* __restrict__ src, float* __restrict__ tmp, int 
 
 __global__ void __launch_bounds__(256)
 blur_cols_rt_kernel(const float* __restrict__ tmp, const float* __restrict__ src, float* __restrict__ dst,
-                    float* __restrict__ dog, int rows, int cols, GKrt gk) {
+                    float* __restrict__ dog, int rows, int cols, GKrt gk, size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    tmp = ZP(tmp); src = ZP(src); dst = ZP(dst);
+    if (dog) dog = ZP(dog);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
     float acc = 0.f;
@@ -274,7 +295,9 @@ blur_cols_rt_kernel(const float* __restrict__ tmp, const float* __restrict__ src
 }
 
 __global__ void __launch_bounds__(256)
-decimate_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst, int rows, int cols) {
+decimate_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst, int rows, int cols, size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    src = ZP(src); dst = ZP(dst);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
     dst[(size_t)y * cols + x] = src[(size_t)(2 * y) * scols + 2 * x];
@@ -346,7 +369,9 @@ __device__ __forceinline__ void stage_flush_block(const Rec* stage, int n_staged
 #define DT_LAYER ((DT_H + 2) * DT_PITCH)
 #define DET_STAGE 128  // candidates a wave stages in LDS before it has to flush on its own
 __global__ void __launch_bounds__(256)
-detect_kernel_generic(PyrTable T, int o, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count) {
+detect_kernel_generic(PyrTable T, int o, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count, size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    cand = ZP(cand); count = ZP(count);
     __shared__ float lds[(MAX_LAY - 1) * DT_LAYER + 64];
     __shared__ uint2 stage_all[4][DET_STAGE];
     __shared__ int wcnt[5];
@@ -360,7 +385,7 @@ detect_kernel_generic(PyrTable T, int o, float thr, uint2* __restrict__ cand, in
         const int l = f / DT_LAYER, rem = f - l * DT_LAYER;
         const int row = rem / DT_PITCH, col = rem - row * DT_PITCH;
         const int gy = min(max(y0 - 1 + row, 0), rows - 1), gx = min(max(x0 - 1 + col, 0), cols - 1);
-        const float* g = T.dog[o][l] + (size_t)gy * cols + gx;
+        const float* g = TD(o, l) + (size_t)gy * cols + gx;
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds + piece * 64), 4, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -409,7 +434,10 @@ detect_kernel_generic(PyrTable T, int o, float thr, uint2* __restrict__ cand, in
 // val >= max(M[i-1], M[i], M[i+1]), with M the 3x3 max that includes val itself.
 #define DS_COLS 62
 __global__ void __launch_bounds__(256)
-detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count) {
+detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count,
+                     size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    cand = ZP(cand); count = ZP(count);
     const int cols = T.cols[o], rows = T.rows[o];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = SIFT_IMG_BORDER + blockIdx.x * DS_COLS + lane - 1;
@@ -422,7 +450,7 @@ detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ 
     const int xc = min(max(x, 0), cols - 1);
     const float* p[5];
 #pragma unroll
-    for (int l = 0; l < 5; ++l) p[l] = T.dog[o][l] + xc;
+    for (int l = 0; l < 5; ++l) p[l] = TD(o, l) + xc;
     const bool col_ok = lane >= 1 && lane <= DS_COLS && x < cols - SIFT_IMG_BORDER;
     float hm[5][3], hn[5][3], cv[3][3];
     auto load_row = [&](int row, int slot) {
@@ -480,7 +508,9 @@ struct TailK { int r[MAX_LAY]; float k[MAX_LAY][2 * RT_MAXR + 1]; };  // slot i 
 
 __global__ void __launch_bounds__(1024)
 pyramid_tail_kernel(PyrTable T, int o_start, TailK gk, float thr, uint2* __restrict__ cand, int cap,
-                    int* __restrict__ count) {
+                    int* __restrict__ count, size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    cand = ZP(cand); count = ZP(count);
     extern __shared__ float smem[];
     float* const g0 = smem;
     float* const tm = smem + 2 * TAIL_MAXPX;
@@ -493,19 +523,19 @@ pyramid_tail_kernel(PyrTable T, int o_start, TailK gk, float thr, uint2* __restr
     for (int o = o_start; o < T.n_oct; ++o) {
         const int rows = T.rows[o], cols = T.cols[o], n = rows * cols;
         if (o == o_start) {
-            const float* up = T.gauss[o - 1][nl];
+            const float* up = TG(o - 1, nl);
             const int ucols = T.cols[o - 1];
             for (int p = tid; p < n; p += 1024) {
                 const int y = p / cols, x = p - y * cols;
                 const float v = up[(size_t)(2 * y) * ucols + 2 * x];
                 g0[p] = v;
-                T.gauss[o][0][p] = v;
+                TG(o, 0)[p] = v;
             }
         } else {
             for (int p = tid; p < n; p += 1024) {
                 const float v = nx[p];
                 g0[p] = v;
-                T.gauss[o][0][p] = v;
+                TG(o, 0)[p] = v;
             }
         }
         __syncthreads();
@@ -527,8 +557,8 @@ pyramid_tail_kernel(PyrTable T, int o_start, TailK gk, float thr, uint2* __restr
             }
             __syncthreads();  // also: every detect below has finished reading the ring slot rewritten next
             float* dslot = dg + ((i - 1) % 3) * TAIL_MAXPX;
-            float* gout = T.gauss[o][i];
-            float* dout = T.dog[o][i - 1];
+            float* gout = TG(o, i);
+            float* dout = TD(o, i - 1);
             for (int p = tid; p < n; p += 1024) {
                 const int y = p / cols, x = p - y * cols;
                 float acc = 0.f;
@@ -680,7 +710,9 @@ __device__ __forceinline__ void tf_mirror(float* __restrict__ A, int rows, int c
 template <int R1, int R2, int R3, int R4, int R5>
 __global__ void __launch_bounds__(1024)
 pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* __restrict__ cand, int cap,
-                         int* __restrict__ count) {
+                         int* __restrict__ count, size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    cand = ZP(cand); count = ZP(count);
     static_assert(R1 <= TF_M && R2 <= TF_M && R3 <= TF_M && R4 <= TF_M && R5 <= TF_M, "margin too small");
     extern __shared__ float smem[];
     float* const A = smem;
@@ -694,9 +726,9 @@ pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* _
     for (int o = o_start; o < T.n_oct; ++o) {
         const int rows = T.rows[o], cols = T.cols[o], n = rows * cols, P = tf_pitch(cols);
         {
-            const float* up = T.gauss[o - 1][T.nl];
+            const float* up = TG(o - 1, T.nl);
             const int ucols = T.cols[o - 1];
-            float* g0 = T.gauss[o][0];
+            float* g0 = TG(o, 0);
             for (int p = tid; p < n; p += 1024) {
                 const int y = p / cols, x = p - y * cols;
                 const float v = o == o_start ? up[(size_t)(2 * y) * ucols + 2 * x] : nx[p];
@@ -747,8 +779,8 @@ pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* _
 #define TF_LAYER(I, R, NX)                                                                                         \
         tf_row_pass<R>(A, tm, gk.k[I - 1], rows, cols, P);                                                         \
         __syncthreads(); /* also: the scan before this is done with the ring slot rewritten next */              \
-        tf_col_pass<R>(A, tm, gk.k[I - 1], rows, cols, P, dg + ((I - 1) % 3) * TAIL_MAXPX, T.gauss[o][I],         \
-                       T.dog[o][I - 1], NX);                                                                       \
+        tf_col_pass<R>(A, tm, gk.k[I - 1], rows, cols, P, dg + ((I - 1) % 3) * TAIL_MAXPX, TG(o, I),         \
+                       TD(o, I - 1), NX);                                                                       \
         __syncthreads();                                                                                           \
         if (I < 5) { tf_mirror(A, rows, cols, P); __syncthreads(); }
         TF_LAYER(1, R1, nullptr)
@@ -779,8 +811,8 @@ __device__ __forceinline__ void solve3(const float a[3][3], const float b[3], fl
                 b[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]));
 }
 
-__device__ __forceinline__ bool refine_one(const PyrTable& T, const uint2 cd, float contrast_thr, float edge_thr,
-                                           float sigma, RefinedKp& k) {
+__device__ __forceinline__ bool refine_one(const PyrTable& T, const size_t zo, const uint2 cd, float contrast_thr,
+                                           float edge_thr, float sigma, RefinedKp& k) {
     const int octv = cd.x >> 8;
     int layer = cd.x & 255, r = cd.y >> 16, c = cd.y & 0xffff;
     const int nl = T.nl, rows = T.rows[octv], cols = T.cols[octv];
@@ -790,9 +822,9 @@ __device__ __forceinline__ bool refine_one(const PyrTable& T, const uint2 cd, fl
     int i = 0;
 #define AT(p, rr, cc) (p)[(size_t)(rr) * cols + (cc)]
     for (; i < SIFT_MAX_INTERP_STEPS; i++) {
-        const float* img = T.dog[octv][layer];
-        const float* prev = T.dog[octv][layer - 1];
-        const float* next = T.dog[octv][layer + 1];
+        const float* img = TD(octv, layer);
+        const float* prev = TD(octv, layer - 1);
+        const float* next = TD(octv, layer + 1);
         const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
                              (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
                              (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
@@ -817,9 +849,9 @@ __device__ __forceinline__ bool refine_one(const PyrTable& T, const uint2 cd, fl
     if (i >= SIFT_MAX_INTERP_STEPS) return false;
     float contr;
     {
-        const float* img = T.dog[octv][layer];
-        const float* prev = T.dog[octv][layer - 1];
-        const float* next = T.dog[octv][layer + 1];
+        const float* img = TD(octv, layer);
+        const float* prev = TD(octv, layer - 1);
+        const float* next = TD(octv, layer + 1);
         const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
                              (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
                              (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
@@ -847,11 +879,13 @@ __device__ __forceinline__ bool refine_one(const PyrTable& T, const uint2 cd, fl
 // host queues this kernel), so the grid is sized by a guess and strides.
 __global__ void __launch_bounds__(256)
 refine_kernel(PyrTable T, const uint2* __restrict__ cand, const int* __restrict__ n_cand_dev, int cap, float contrast_thr,
-              float edge_thr, float sigma, RefinedKp* __restrict__ out, int* __restrict__ count) {
+              float edge_thr, float sigma, RefinedKp* __restrict__ out, int* __restrict__ count, size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    cand = ZP(cand); n_cand_dev = ZP(n_cand_dev); out = ZP(out); count = ZP(count);
     const int n_cand = min(*n_cand_dev, cap);
     for (int id = blockIdx.x * 256 + threadIdx.x; id < n_cand; id += gridDim.x * 256) {
         RefinedKp k;
-        if (refine_one(T, cand[id], contrast_thr, edge_thr, sigma, k)) out[atomicAdd(count, 1)] = k;
+        if (refine_one(T, zo, cand[id], contrast_thr, edge_thr, sigma, k)) out[atomicAdd(count, 1)] = k;
     }
 }
 
@@ -867,7 +901,9 @@ __device__ __forceinline__ float atan2_deg(float y, float x) {
 #define ORI_STAGE 64
 __global__ void __launch_bounds__(256)
 orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restrict__ n_ref_dev, int ref_cap,
-              KpRec* __restrict__ out, int cap, int* __restrict__ count) {
+              KpRec* __restrict__ out, int cap, int* __restrict__ count, size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    ref = ZP(ref); n_ref_dev = ZP(n_ref_dev); out = ZP(out); count = ZP(count);
     __shared__ unsigned long long hacc[4][SIFT_ORI_HIST_BINS];
     __shared__ float hsm[4][SIFT_ORI_HIST_BINS + 4];
     __shared__ KpRec stage_all[4][ORI_STAGE];
@@ -886,7 +922,7 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
         if (active) {
             k = ref[id];
             const int rows = T.rows[k.o], cols = T.cols[k.o];
-            const float* img = T.gauss[k.o][k.layer];
+            const float* img = TG(k.o, k.layer);
             const float scl_octv = k.size * 0.5f / (1 << k.o);
             const int radius = __float2int_rn(4.5f * scl_octv);
             const float sigma = 1.5f * scl_octv;
@@ -955,7 +991,11 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
 #define DESC_HIST (6 * 6 * 10)
 template <int WPK>
 __global__ void __launch_bounds__(256)
-describe_kernel(PyrTable T, const KpRec* __restrict__ kps, int n_kp, int first_octave, uint8_t* __restrict__ desc) {
+describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first_octave, uint8_t* __restrict__ desc,
+                size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    kps = ZP(kps); desc = ZP(desc);
+    const int n_kp = seg.off[blockIdx.z + 1] - seg.off[blockIdx.z];
     constexpr int GROUPS = 4 / WPK, GL = 64 * WPK;
     __shared__ unsigned long long hist[GROUPS][DESC_HIST];
     const int lane = threadIdx.x & 63, wave = threadIdx.x / GL, gl = threadIdx.x % GL;
@@ -973,7 +1013,7 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, int n_kp, int first_o
         const float size = kp.size * scale;
         const float ptx = kp.x * scale, pty = kp.y * scale;
         const int o = octave - first_octave;
-        const float* img = T.gauss[o][layer];
+        const float* img = TG(o, layer);
         const int rows = T.rows[o], cols = T.cols[o];
         float ori = 360.f - kp.angle;
         if (fabsf(ori - 360.f) < FLT_EPSILON) ori = 0.f;
@@ -1091,37 +1131,38 @@ static int gauss_kernel(double sigma, float* k, int maxn) {
 }
 
 template <int R>
-static void launch_blur_fixed(hipStream_t st, const float* src, float* dst, float* dog, int rows, int cols, const float* k) {
+static void launch_blur_fixed(hipStream_t st, const float* src, float* dst, float* dog, int rows, int cols, const float* k,
+                              int batch, size_t zs) {
     GK<R> gk;
     memcpy(gk.k, k, sizeof(gk.k));
-    hipLaunchKernelGGL(blur_kernel<R>, dim3((cols + 63) / 64, (rows + 31) / 32), dim3(256), 0, st, src, dst, dog,
-                       rows, cols, gk);
+    hipLaunchKernelGGL(blur_kernel<R>, dim3((cols + 63) / 64, (rows + 31) / 32, batch), dim3(256), 0, st, src, dst, dog,
+                       rows, cols, gk, zs);
 }
 
 // GaussianBlur(src, dst, Size(), sigma) [+ dog = dst - src]; tmp: scratch of the same size (runtime-radius path)
 static bool blur_radius_is_templated(int r) { return r == 4 || r == 5 || r == 6 || r == 8 || r == 10 || r == 13; }
 
 static int gaussian_blur(imatch_ctx* ctx, hipStream_t st, const float* src, float* dst, float* dog, float* tmp, int rows,
-                         int cols, double sigma) {
+                         int cols, double sigma, int batch, size_t zs) {
     float k[2 * RT_MAXR + 1];
     const int n = gauss_kernel(sigma, k, 2 * RT_MAXR + 1);
     if (n < 0) return imatch_set_err(ctx, IMATCH_ESIZE, "Gaussian sigma %g needs a kernel wider than %d", sigma, 2 * RT_MAXR + 1);
     const int r = n / 2;
     switch (r) {
-        case 4: launch_blur_fixed<4>(st, src, dst, dog, rows, cols, k); break;
-        case 5: launch_blur_fixed<5>(st, src, dst, dog, rows, cols, k); break;
-        case 6: launch_blur_fixed<6>(st, src, dst, dog, rows, cols, k); break;
-        case 8: launch_blur_fixed<8>(st, src, dst, dog, rows, cols, k); break;
-        case 10: launch_blur_fixed<10>(st, src, dst, dog, rows, cols, k); break;
-        case 13: launch_blur_fixed<13>(st, src, dst, dog, rows, cols, k); break;
+        case 4: launch_blur_fixed<4>(st, src, dst, dog, rows, cols, k, batch, zs); break;
+        case 5: launch_blur_fixed<5>(st, src, dst, dog, rows, cols, k, batch, zs); break;
+        case 6: launch_blur_fixed<6>(st, src, dst, dog, rows, cols, k, batch, zs); break;
+        case 8: launch_blur_fixed<8>(st, src, dst, dog, rows, cols, k, batch, zs); break;
+        case 10: launch_blur_fixed<10>(st, src, dst, dog, rows, cols, k, batch, zs); break;
+        case 13: launch_blur_fixed<13>(st, src, dst, dog, rows, cols, k, batch, zs); break;
         default: {
             GKrt gk;
             gk.r = r;
             memcpy(gk.k, k, sizeof(float) * n);
-            const dim3 grid((cols + 63) / 64, (rows + 3) / 4);
-            hipLaunchKernelGGL(blur_rows_rt_kernel, grid, dim3(256), 0, st, src, tmp, rows, cols, gk);
+            const dim3 grid((cols + 63) / 64, (rows + 3) / 4, batch);
+            hipLaunchKernelGGL(blur_rows_rt_kernel, grid, dim3(256), 0, st, src, tmp, rows, cols, gk, zs);
             hipLaunchKernelGGL(blur_cols_rt_kernel, grid, dim3(256), 0, st, (const float*)tmp, src, dst, dog, rows,
-                               cols, gk);
+                               cols, gk, zs);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1181,10 +1222,17 @@ static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 
 extern "C" {
 
-static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, int h, int w, int stride,
-                        const imatch_sift_params* P, imatch_features** out) {
-    if (!ctx || !img || !P || !out || h <= 0 || w <= 0 || stride < w)
+// One extraction of `batch` equally sized images: image b is img + b * img_pitch bytes. Every kernel is
+// launched once for the whole batch (gridDim.z = batch) over `batch` copies of the per-image arena
+// layout, zs bytes apart; on a camera frame the launches are latency-bound, so a batch costs little
+// more than one image. The result is ONE descriptor set holding the images' rows back to back;
+// offsets[b] .. offsets[b+1] are image b's rows (and keypoint records).
+static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, int batch, size_t img_pitch, int h, int w,
+                        int stride, const imatch_sift_params* P, imatch_features** out, int64_t* offsets) {
+    if (!ctx || !img || !P || !out || h <= 0 || w <= 0 || stride < w || batch < 1)
         return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    if (batch > IMATCH_MAX_BATCH) return imatch_set_err(ctx, IMATCH_ESIZE, "batch %d above %d", batch, IMATCH_MAX_BATCH);
+    if (batch > 1 && (!img_on_device || !offsets)) return imatch_set_err(ctx, IMATCH_EINVAL, "a batch needs device images and offsets");
     if (P->n_octave_layers < 1 || P->n_octave_layers + 3 > MAX_LAY)
         return imatch_set_err(ctx, IMATCH_ESIZE, "nOctaveLayers %d outside 1..%d", P->n_octave_layers, MAX_LAY - 3);
     if (h > 16384 || w > 16384) return imatch_set_err(ctx, IMATCH_ESIZE, "image larger than 16384 on a side");
@@ -1198,7 +1246,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
     if (n_oct < 1) n_oct = 1;
     if (n_oct > MAX_OCT) n_oct = MAX_OCT;
 
-    // ---- arena layout
+    // ---- arena layout of ONE image (every offset is relative to the image's block)
     if (!ctx->sift) {
         ctx->sift = (imatch_sift_state*)calloc(1, sizeof(imatch_sift_state));
         if (!ctx->sift) return imatch_set_err(ctx, IMATCH_ENOMEM, "host alloc");
@@ -1230,7 +1278,8 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         const size_t o_cand = take((size_t)cap * sizeof(uint2));
         const size_t o_ref = take((size_t)cap * sizeof(RefinedKp));
         const size_t o_kp = take((size_t)cap * 2 * sizeof(KpRec));
-        const size_t need = off;
+        const size_t zs = (off + 4095) & ~(size_t)4095;   // bytes between the blocks of consecutive images
+        const size_t need = zs * (size_t)batch;
         if (need > S->arena_bytes) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (S->arena) HIP_TRY(ctx, hipFree(S->arena));
@@ -1257,22 +1306,33 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         RefinedKp* d_ref = (RefinedKp*)(A + o_ref);
         KpRec* d_kp = (KpRec*)(A + o_kp);
 
-        // ---- pre-processing + pyramid
-        HIP_TRY(ctx, hipMemcpy2DAsync(d_img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
-                                      img_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        // ---- pre-processing + pyramid. Device images with dense rows are read where they lie.
         const uint8_t* d_src = d_img;
+        int src_stride = w;
+        size_t src_zs = zs;
+        if (img_on_device && (stride == w || batch > 1)) {
+            d_src = img;
+            src_stride = stride;
+            src_zs = img_pitch;
+        } else {
+            HIP_TRY(ctx, hipMemcpy2DAsync(d_img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
+                                          img_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        }
         if (P->clahe) {
-            int rc = imatch_clahe_dev(ctx, d_img, h, w, w, P->clahe_clip, P->clahe_tiles_x, P->clahe_tiles_y, d_clahe,
-                                      A + o_cscr);
+            int rc = imatch_clahe_dev(ctx, d_src, h, w, src_stride, P->clahe_clip, P->clahe_tiles_x, P->clahe_tiles_y, d_clahe,
+                                      A + o_cscr, batch, src_zs, zs);
             if (rc) return rc;
             d_src = d_clahe;
+            src_stride = w;
+            src_zs = zs;
         }
-        HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
+        if (batch == 1) HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
+        else HIP_TRY(ctx, hipMemset2DAsync(d_cnt, zs, 0, 256, (size_t)batch, ctx->stream));
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
-        hipLaunchKernelGGL(upsample2_kernel, dim3((bcols + 63) / 64, (brows + 3) / 4), dim3(256), 0, ctx->stream, d_src, h,
-                           w, w, d_up);
+        hipLaunchKernelGGL(upsample2_kernel, dim3((bcols + 63) / 64, (brows + 3) / 4, batch), dim3(256), 0, ctx->stream, d_src,
+                           h, w, src_stride, d_up, src_zs, zs);
         const float sig_diff = sqrtf(fmaxf((float)P->sigma * (float)P->sigma - 0.5f * 0.5f * 4, 0.01f));
-        int rc = gaussian_blur(ctx, ctx->stream, d_up, T.gauss[0][0], nullptr, d_tmp, brows, bcols, sig_diff);
+        int rc = gaussian_blur(ctx, ctx->stream, d_up, T.gauss[0][0], nullptr, d_tmp, brows, bcols, sig_diff, batch, zs);
         if (rc) return rc;
         double sig[MAX_LAY];
         sig[0] = P->sigma;
@@ -1288,7 +1348,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // fork/join (see imatch_sift_state); the runtime-radius blur shares d_tmp, so it stays on one stream
         // An event record + cross-stream wait costs ~20 us per octave (tools/launch_bench.hip), more than a
         // camera frame's octave gains; on a map the overlap fills the tails of the big launches.
-        bool use_side = (size_t)brows * bcols >= ((size_t)1 << 22);
+        bool use_side = (size_t)brows * bcols * batch >= ((size_t)1 << 22);
         for (int i = 1; i < nl + 3; ++i) {
             float kk[2 * RT_MAXR + 1];
             const int n = gauss_kernel(sig[i], kk, 2 * RT_MAXR + 1);
@@ -1303,10 +1363,11 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         for (int o = 0; o < o_tail; ++o) {
             const int rows = T.rows[o], cols = T.cols[o];
             if (o > 0)
-                hipLaunchKernelGGL(decimate_kernel, dim3((cols + 63) / 64, (rows + 3) / 4), dim3(256), 0, ctx->stream,
-                                   (const float*)T.gauss[o - 1][nl], T.cols[o - 1], T.gauss[o][0], rows, cols);
+                hipLaunchKernelGGL(decimate_kernel, dim3((cols + 63) / 64, (rows + 3) / 4, batch), dim3(256), 0, ctx->stream,
+                                   (const float*)T.gauss[o - 1][nl], T.cols[o - 1], T.gauss[o][0], rows, cols, zs);
             for (int i = 1; i <= nl; ++i) {
-                rc = gaussian_blur(ctx, ctx->stream, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i]);
+                rc = gaussian_blur(ctx, ctx->stream, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i],
+                                   batch, zs);
                 if (rc) return rc;
             }
             if (use_side) {
@@ -1314,19 +1375,20 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                 HIP_TRY(ctx, hipStreamWaitEvent(st2, S->ev_fork[o], 0));
             }
             for (int i = nl + 1; i < nl + 3; ++i) {
-                rc = gaussian_blur(ctx, st2, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i]);
+                rc = gaussian_blur(ctx, st2, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i], batch, zs);
                 if (rc) return rc;
             }
             if (rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER) {
                 const int iw = cols - 2 * SIFT_IMG_BORDER, ih = rows - 2 * SIFT_IMG_BORDER;
                 if (nl == 3) {
-                    const size_t px = (size_t)iw * ih;
+                    const size_t px = (size_t)iw * ih * batch;
                     const int rpw = px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
-                    hipLaunchKernelGGL(detect_stream_kernel, dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * rpw - 1) / (4 * rpw)),
-                                       dim3(256), 0, st2, T, o, rpw, thr, d_cand, cap, d_cnt);
+                    hipLaunchKernelGGL(detect_stream_kernel,
+                                       dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * rpw - 1) / (4 * rpw), batch), dim3(256), 0, st2,
+                                       T, o, rpw, thr, d_cand, cap, d_cnt, zs);
                 } else {
-                    hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H), dim3(256),
-                                       0, st2, T, o, thr, d_cand, cap, d_cnt);
+                    hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H, batch),
+                                       dim3(256), 0, st2, T, o, thr, d_cand, cap, d_cnt, zs);
                 }
             }
         }
@@ -1348,8 +1410,8 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS_BYTES));
                 attr_set[ctx->device & 63] = true;
             }
-            hipLaunchKernelGGL((pyramid_tail_fast_kernel<5, 6, 8, 10, 13>), dim3(1), dim3(1024), TF_LDS_BYTES, ctx->stream, T,
-                               o_tail, tfk, thr, d_cand, cap, d_cnt);
+            hipLaunchKernelGGL((pyramid_tail_fast_kernel<5, 6, 8, 10, 13>), dim3(1, 1, batch), dim3(1024), TF_LDS_BYTES,
+                               ctx->stream, T, o_tail, tfk, thr, d_cand, cap, d_cnt, zs);
         } else if (o_tail < n_oct) {
             TailK tk;
             memset(&tk, 0, sizeof(tk));
@@ -1364,8 +1426,8 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                                                  TAIL_LDS_BYTES));
                 attr_set[ctx->device & 63] = true;
             }
-            hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1), dim3(1024), TAIL_LDS_BYTES, ctx->stream, T, o_tail, tk, thr,
-                               d_cand, cap, d_cnt);
+            hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1, 1, batch), dim3(1024), TAIL_LDS_BYTES, ctx->stream, T, o_tail, tk,
+                               thr, d_cand, cap, d_cnt, zs);
         }
         HIP_TRY(ctx, hipGetLastError());
         if (use_side) {
@@ -1374,67 +1436,97 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         }
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
         // ---- refine + orientation are queued behind the scan without waiting for its count
-        hipLaunchKernelGGL(refine_kernel, dim3(std::min((cap + 255) / 256, 1024)), dim3(256), 0, ctx->stream, T,
+        hipLaunchKernelGGL(refine_kernel, dim3(std::min((cap + 255) / 256, 1024), 1, batch), dim3(256), 0, ctx->stream, T,
                            (const uint2*)d_cand, (const int*)d_cnt, cap, (float)P->contrast_threshold,
-                           (float)P->edge_threshold, (float)P->sigma, d_ref, d_cnt + 1);
+                           (float)P->edge_threshold, (float)P->sigma, d_ref, d_cnt + 1, zs);
         const int ref_hint = S->ref_hint > 0 ? S->ref_hint : 4096;
-        hipLaunchKernelGGL(orient_kernel, dim3(std::min(std::max((ref_hint + 3) / 4, 64), 4096)), dim3(256), 0, ctx->stream,
-                           T, (const RefinedKp*)d_ref, (const int*)(d_cnt + 1), cap, d_kp, 2 * cap, d_cnt + 2);
+        hipLaunchKernelGGL(orient_kernel, dim3(std::min(std::max((ref_hint + 3) / 4, 64), 4096), 1, batch), dim3(256), 0,
+                           ctx->stream, T, (const RefinedKp*)d_ref, (const int*)(d_cnt + 1), cap, d_kp, 2 * cap, d_cnt + 2, zs);
         HIP_TRY(ctx, hipGetLastError());
-        // ---- the extraction's one synchronisation: the three counters and (a guess of) the records
-        const int kp_hint = std::min(2 * cap, S->kp_hint > 0 ? S->kp_hint : 8192);
-        rc = imatch_hs_reserve(ctx, 256 + (size_t)kp_hint * sizeof(KpRec));
+        // ---- the extraction's one synchronisation: the counters and (a guess of) the records of every image
+        int kp_hint = std::min(2 * cap, S->kp_hint > 0 ? S->kp_hint : 8192);
+        const size_t cnt_bytes = al((size_t)batch * 16);
+        rc = imatch_hs_reserve(ctx, cnt_bytes + (size_t)batch * kp_hint * sizeof(KpRec));
         if (rc) return rc;
-        int* h_cnt = (int*)ctx->hs;
-        KpRec* h_kp = (KpRec*)((char*)ctx->hs + 256);
-        HIP_TRY(ctx, hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(h_kp, d_kp, (size_t)kp_hint * sizeof(KpRec), hipMemcpyDeviceToHost, ctx->stream));
+        int* h_cnt = (int*)ctx->hs;                              // [batch][4]
+        KpRec* h_kp = (KpRec*)((char*)ctx->hs + cnt_bytes);      // [batch][kp_hint]
+        HIP_TRY(ctx, hipMemcpy2DAsync(h_cnt, 16, d_cnt, zs, 16, (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), d_kp, zs, (size_t)kp_hint * sizeof(KpRec),
+                                      (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        const int n_cand = h_cnt[0], n_ref = h_cnt[1], n_kp = h_cnt[2];
-        if (n_cand > cap) {  // rare: grow the lists and run the frame again
-            cap = n_cand + n_cand / 8;
+        int max_cand = 0, max_ref = 0, max_kp = 0;
+        for (int b = 0; b < batch; ++b) {
+            max_cand = std::max(max_cand, h_cnt[4 * b]);
+            max_ref = std::max(max_ref, h_cnt[4 * b + 1]);
+            max_kp = std::max(max_kp, h_cnt[4 * b + 2]);
+        }
+        if (max_cand > cap) {  // rare: grow the lists and run the batch again
+            cap = max_cand + max_cand / 8;
             continue;
         }
-        if (n_kp > 2 * cap) {
-            cap = n_kp;
+        if (max_kp > 2 * cap) {
+            cap = max_kp;
             continue;
         }
-        S->ref_hint = n_ref + n_ref / 4 + 256;
-        S->kp_hint = n_kp + n_kp / 4 + 1024;
-        if (n_kp > kp_hint) {
-            rc = imatch_hs_reserve(ctx, 256 + (size_t)n_kp * sizeof(KpRec));  // may move hs: copy everything again
+        S->ref_hint = max_ref + max_ref / 4 + 256;
+        S->kp_hint = max_kp + max_kp / 4 + 1024;
+        std::vector<int> n_kp((size_t)batch);
+        for (int b = 0; b < batch; ++b) n_kp[b] = h_cnt[4 * b + 2];
+        if (max_kp > kp_hint) {  // the guess was short: fetch everything again at the right width
+            kp_hint = max_kp;
+            rc = imatch_hs_reserve(ctx, cnt_bytes + (size_t)batch * kp_hint * sizeof(KpRec));  // may move hs
             if (rc) return rc;
-            h_kp = (KpRec*)((char*)ctx->hs + 256);
-            HIP_TRY(ctx, hipMemcpyAsync(h_kp, d_kp, (size_t)n_kp * sizeof(KpRec), hipMemcpyDeviceToHost, ctx->stream));
+            h_kp = (KpRec*)((char*)ctx->hs + cnt_bytes);
+            HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), d_kp, zs, (size_t)kp_hint * sizeof(KpRec),
+                                          (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
-        // ---- removeDuplicatedSorted + first-octave rescale on the host (K records of 24 bytes)
-        std::vector<KpRec> kps((size_t)n_kp);
-        if (n_kp > 0) {
-            sort_keypoints(h_kp, n_kp, kps.data());
-            size_t j = 0;
-            for (size_t i = 1; i < kps.size(); ++i) {
-                const KpRec &a = kps[j], &b = kps[i];
-                if (a.x != b.x || a.y != b.y || a.size != b.size || a.angle != b.angle) kps[++j] = kps[i];
-            }
-            kps.resize(j + 1);
-            for (auto& k : kps) {
+        // ---- removeDuplicatedSorted + first-octave rescale on the host (K records of 24 bytes per image);
+        // the sorted records go back into the same pinned rows
+        SegTab seg;
+        memset(&seg, 0, sizeof(seg));
+        seg.n = batch;
+        std::vector<KpRec> kps;
+        int max_k = 0;
+        for (int b = 0; b < batch; ++b) {
+            KpRec* rec = h_kp + (size_t)b * kp_hint;
+            int K = 0;
+            if (n_kp[b] > 0) {
+                kps.resize((size_t)n_kp[b]);
+                sort_keypoints(rec, n_kp[b], kps.data());
+                size_t j = 0;
+                for (size_t i = 1; i < kps.size(); ++i) {
+                    const KpRec &a = kps[j], &c = kps[i];
+                    if (a.x != c.x || a.y != c.y || a.size != c.size || a.angle != c.angle) kps[++j] = kps[i];
+                }
+                K = (int)j + 1;
                 const float scale = 1.f / (float)(1 << -first_octave);
-                k.octave = (k.octave & ~255) | ((k.octave + first_octave) & 255);
-                k.x *= scale; k.y *= scale; k.size *= scale;
+                for (int i = 0; i < K; ++i) {
+                    KpRec& k = kps[i];
+                    k.octave = (k.octave & ~255) | ((k.octave + first_octave) & 255);
+                    k.x *= scale; k.y *= scale; k.size *= scale;
+                }
+                memcpy(rec, kps.data(), (size_t)K * sizeof(KpRec));
+            }
+            seg.off[b + 1] = seg.off[b] + K;
+            max_k = std::max(max_k, K);
+        }
+        const int Ktot = seg.off[batch];
+        imatch_features* f = nullptr;
+        rc = imatch_features_alloc(ctx, Ktot, &f);
+        if (rc) return rc;
+        f->kp = (float*)malloc(sizeof(float) * 7 * (size_t)std::max(Ktot, 1));
+        for (int b = 0; b < batch; ++b) {
+            const KpRec* rec = h_kp + (size_t)b * kp_hint;
+            for (int i = 0; i < seg.off[b + 1] - seg.off[b]; ++i) {
+                float* p = f->kp + 7 * (size_t)(seg.off[b] + i);
+                p[0] = rec[i].x; p[1] = rec[i].y; p[2] = rec[i].size; p[3] = rec[i].angle; p[4] = rec[i].response;
+                p[5] = (float)rec[i].octave; p[6] = -1.f;
             }
         }
-        const int K = (int)kps.size();
-        imatch_features* f = nullptr;
-        rc = imatch_features_alloc(ctx, K, &f);
-        if (rc) return rc;
-        f->kp = (float*)malloc(sizeof(float) * 7 * (size_t)std::max(K, 1));
-        for (int i = 0; i < K; ++i) {
-            float* p = f->kp + 7 * (size_t)i;
-            p[0] = kps[i].x; p[1] = kps[i].y; p[2] = kps[i].size; p[3] = kps[i].angle; p[4] = kps[i].response;
-            p[5] = (float)kps[i].octave; p[6] = -1.f;
-        }
-        if (P->clahe) {
+        if (offsets)
+            for (int b = 0; b <= batch; ++b) offsets[b] = seg.off[b];
+        if (P->clahe && batch == 1) {
             f->image = (uint8_t*)imatch_pool_alloc(ctx, (size_t)h * w);
             if (!f->image) {
                 imatch_features_free(f);
@@ -1446,24 +1538,25 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // sorted records and u8 descriptors reuse the candidate / refined lists (no longer needed)
         KpRec* d_sorted = (KpRec*)d_ref;
         uint8_t* d_desc = (uint8_t*)d_kp;  // cap*2*24 bytes >= K*128 needs K <= cap*0.375: checked below
-        if ((size_t)K * 128 > (size_t)cap * 2 * sizeof(KpRec) || (size_t)K * sizeof(KpRec) > (size_t)cap * sizeof(RefinedKp)) {
+        if ((size_t)max_k * 128 > (size_t)cap * 2 * sizeof(KpRec) || (size_t)max_k * sizeof(KpRec) > (size_t)cap * sizeof(RefinedKp)) {
             imatch_features_free(f);
-            cap = (int)((size_t)K * 3 + 1024);
+            cap = (int)((size_t)max_k * 3 + 1024);
             continue;
         }
-        if (K > 0) {
-            // staged in the pinned block (K <= n_kp records fit), which nothing rewrites before the next synchronisation
-            memcpy(h_kp, kps.data(), (size_t)K * sizeof(KpRec));
-            HIP_TRY(ctx, hipMemcpyAsync(d_sorted, h_kp, (size_t)K * sizeof(KpRec), hipMemcpyHostToDevice, ctx->stream));
-            if (K <= 65536)
-                hipLaunchKernelGGL(describe_kernel<4>, dim3(K), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted, K,
-                                   first_octave, d_desc);
+        if (Ktot > 0) {
+            // the pinned rows are not rewritten before the next synchronisation on this context
+            HIP_TRY(ctx, hipMemcpy2DAsync(d_sorted, zs, h_kp, (size_t)kp_hint * sizeof(KpRec), (size_t)max_k * sizeof(KpRec),
+                                          (size_t)batch, hipMemcpyHostToDevice, ctx->stream));
+            if (max_k <= 65536)
+                hipLaunchKernelGGL(describe_kernel<4>, dim3(max_k, 1, batch), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted,
+                                   seg, first_octave, d_desc, zs);
             else
-                hipLaunchKernelGGL(describe_kernel<1>, dim3((K + 3) / 4), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted,
-                                   K, first_octave, d_desc);
+                hipLaunchKernelGGL(describe_kernel<1>, dim3((max_k + 3) / 4, 1, batch), dim3(256), 0, ctx->stream, T,
+                                   (const KpRec*)d_sorted, seg, first_octave, d_desc, zs);
             HIP_TRY(ctx, hipGetLastError());
         }
-        rc = imatch_features_pack_u8_dev(ctx, f, d_desc);  // bf16 rows + norms, queued (u8 rows are integral by type)
+        // bf16 rows + norms of the concatenated set, queued (u8 rows are integral by type)
+        rc = batch == 1 ? imatch_features_pack_u8_dev(ctx, f, d_desc) : imatch_features_pack_u8_seg_dev(ctx, f, d_desc, &seg, zs);
         if (rc) { imatch_features_free(f); return rc; }
         *out = f;
         return IMATCH_OK;
@@ -1473,12 +1566,19 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
 
 int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, const imatch_sift_params* P,
                         imatch_features** out) {
-    return sift_extract(ctx, img, 0, h, w, stride, P, out);
+    return sift_extract(ctx, img, 0, 1, 0, h, w, stride, P, out, nullptr);
 }
 
 int imatch_sift_extract_dev(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int stride,
                             const imatch_sift_params* P, imatch_features** out) {
-    return sift_extract(ctx, img_dev, 1, h, w, stride, P, out);
+    return sift_extract(ctx, img_dev, 1, 1, 0, h, w, stride, P, out, nullptr);
+}
+
+int imatch_sift_extract_batch_dev(imatch_ctx* ctx, const uint8_t* img_dev, int n_img, size_t img_pitch, int h, int w,
+                                  int stride, const imatch_sift_params* P, imatch_features** out, int64_t* offsets) {
+    if (img_pitch < (size_t)stride * (size_t)(h > 0 ? h : 0) && n_img > 1)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "image pitch smaller than one image");
+    return sift_extract(ctx, img_dev, 1, n_img, img_pitch, h, w, stride, P, out, offsets);
 }
 
 int imatch_features_download(const imatch_features* f, float* kp, float* desc) {

@@ -100,6 +100,15 @@ int imatch_sift_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int s
  * pipeline that decodes on the GPU; the reference has no device images). */
 int imatch_sift_extract_dev(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int stride,
                             const imatch_sift_params* params, imatch_features** out);
+/* Batched form (no reference counterpart: the reference handles one /photo message at a time,
+ * PF:159-224; this is BASELINE configs[4], many frames per launch). n_img equally sized u8 images in
+ * device memory, image b at img_dev + b * img_pitch bytes (n_img <= 64). Every kernel runs once for
+ * the whole batch. The result is ONE descriptor set with the images' rows back to back:
+ * offsets[b] .. offsets[b+1] (n_img + 1 entries) are image b's rows and keypoint records; each
+ * image's rows are exactly what imatch_sift_extract_dev returns for it. No image copy is kept. */
+int imatch_sift_extract_batch_dev(imatch_ctx* ctx, const uint8_t* img_dev, int n_img, size_t img_pitch, int h, int w,
+                                  int stride, const imatch_sift_params* params, imatch_features** out,
+                                  int64_t* offsets);
 /* kp: [K][7] = x, y, size, angle, response, octave, class_id (cv2.KeyPoint fields, OpenCV's final
  * order: sorted and de-duplicated as KeyPointsFilter::removeDuplicatedSorted leaves them);
  * desc: [K][128] f32, integer valued 0..255. Either pointer may be null. */
@@ -134,6 +143,14 @@ int imatch_merge_top2_dev(imatch_ctx* ctx, const int32_t* in4_dev, int n_lists, 
  * survivors in query order. good_q/good_t/good_d are host arrays of capacity nq. */
 int imatch_ratio_dev(imatch_ctx* ctx, const int32_t* out4_dev, int64_t nq, double ratio,
                      int32_t* good_q, int32_t* good_t, float* good_d, int64_t* n_good);
+/* The same test on the rows of a batch (no reference counterpart; pairs with
+ * imatch_sift_extract_batch_dev): segment b = queries offsets[b] .. offsets[b+1] (offsets[0] = 0,
+ * n_seg <= 64). Segment b's survivors are good_*[good_offsets[b] .. good_offsets[b+1]) with
+ * good_q LOCAL to the segment, i.e. what imatch_ratio_dev returns for that image alone.
+ * good_* have capacity offsets[n_seg]; good_offsets has n_seg + 1 entries. */
+int imatch_ratio_batch_dev(imatch_ctx* ctx, const int32_t* out4_dev, const int64_t* offsets, int n_seg,
+                           double ratio, int32_t* good_q, int32_t* good_t, float* good_d,
+                           int64_t* good_offsets);
 
 /* Robust homography -------------------------------------------------------- */
 /* Replaces cv2.findHomography(src_pts, dst_pts, cv2.USAC_MAGSAC, thr) (MF:233). src/dst are f32
@@ -144,6 +161,13 @@ int imatch_ratio_dev(imatch_ctx* ctx, const int32_t* out4_dev, int64_t nq, doubl
  * `seed` makes the sampling reproducible. mask may be null. */
 int imatch_homography(imatch_ctx* ctx, const float* src, const float* dst, int n, double thr,
                       uint64_t seed, double* H, uint8_t* mask, int* found);
+/* n_seg independent problems in one launch (no reference counterpart; pairs with the batch entry
+ * points above): problem b is src/dst rows offsets[b] .. offsets[b+1] with sampler seed seeds[b];
+ * H is [n_seg][9], found [n_seg], mask [offsets[n_seg]] (may be null). Each problem's result equals
+ * imatch_homography on its rows with its seed. */
+int imatch_homography_batch(imatch_ctx* ctx, const float* src, const float* dst, const int64_t* offsets,
+                            int n_seg, double thr, const uint64_t* seeds, double* H, uint8_t* mask,
+                            int* found);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,99 @@
+"""GPU parity of the batched entry points: every image of a batch must get exactly what the
+single-image entry points give it (keypoints, descriptors, good matches, homography)."""
+import numpy as np
+import pytest
+import torch
+
+import image_matching_amd as im
+from image_matching_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene():
+    m = synth.synth_map(1024, seed=7)
+    frames = [synth.synth_frame(m, i, size=(240, 320))[0] for i in range(5)]
+    return m, frames
+
+
+@pytest.mark.parametrize("clahe", [True, False])
+def test_extract_batch_equals_single(ctx, scene, clahe):
+    _, frames = scene
+    dev = torch.device("cuda", 0)
+    stack = torch.from_numpy(np.stack(frames)).to(dev)
+    params = im.SiftParams(clahe=clahe)
+    f, offs = ctx.sift_extract_batch_dev(stack.data_ptr(), len(frames), 240 * 320, 240, 320, 320, params)
+    kp, desc = f.download()
+    assert offs[0] == 0 and offs[-1] == len(f) and np.all(np.diff(offs) > 50)
+    for b, fr in enumerate(frames):
+        one = ctx.sift_extract(fr, params)
+        kp1, desc1 = one.download()
+        assert np.array_equal(kp[offs[b]:offs[b + 1]], kp1), b
+        assert np.array_equal(desc[offs[b]:offs[b + 1]], desc1), b
+        one.free()
+    f.free()
+
+
+def test_batch_of_one_and_ragged_pitch(ctx, scene):
+    _, frames = scene
+    dev = torch.device("cuda", 0)
+    # images 100 KB apart, rows 384 bytes apart
+    buf = torch.zeros((3, 102400), dtype=torch.uint8, device=dev)
+    for b in range(3):
+        pad = np.zeros((240, 384), np.uint8)
+        pad[:, :320] = frames[b]
+        buf[b, :240 * 384] = torch.from_numpy(pad.reshape(-1)).to(dev)
+    f, offs = ctx.sift_extract_batch_dev(buf.data_ptr(), 3, 102400, 240, 320, 384)
+    kp, desc = f.download()
+    for b in range(3):
+        one = ctx.sift_extract(frames[b])
+        kp1, desc1 = one.download()
+        assert np.array_equal(kp[offs[b]:offs[b + 1]], kp1) and np.array_equal(desc[offs[b]:offs[b + 1]], desc1)
+    f1, o1 = ctx.sift_extract_batch_dev(buf.data_ptr(), 1, 102400, 240, 320, 384)
+    assert o1.tolist() == [0, offs[1]]
+
+
+def test_match_chain_batch_equals_single(ctx, scene):
+    m, frames = scene
+    dev = torch.device("cuda", 0)
+    f_map = ctx.sift_extract(m)
+    map_xy = f_map.download(descriptors=False)[0][:, :2]
+    stack = torch.from_numpy(np.stack(frames)).to(dev)
+    f, offs = ctx.sift_extract_batch_dev(stack.data_ptr(), len(frames), 240 * 320, 240, 320, 320)
+    kp = f.download(descriptors=False)[0]
+    out4 = torch.empty((len(f), 4), dtype=torch.int32, device=dev)
+    ctx.knn2_dev(f, f_map, out4.data_ptr())
+    gq, gt, gd, goff = ctx.ratio_batch_dev(out4.data_ptr(), offs, 0.7)
+    src = np.concatenate([kp[offs[b] + gq[goff[b]:goff[b + 1]], :2] for b in range(len(frames))])
+    H, mask, found = ctx.homography_batch(src, map_xy[gt], goff, 0.1, seeds=np.arange(len(frames)))
+    for b, fr in enumerate(frames):
+        one = ctx.sift_extract(fr)
+        o1 = torch.empty((len(one), 4), dtype=torch.int32, device=dev)
+        ctx.knn2_dev(one, f_map, o1.data_ptr())
+        ctx.synchronize()
+        assert torch.equal(o1, out4[offs[b]:offs[b + 1]])
+        q1, t1, d1 = ctx.ratio_dev(o1.data_ptr(), len(one), 0.7)
+        assert np.array_equal(q1, gq[goff[b]:goff[b + 1]]) and np.array_equal(t1, gt[goff[b]:goff[b + 1]])
+        assert np.array_equal(d1, gd[goff[b]:goff[b + 1]])
+        kp1 = one.download(descriptors=False)[0]
+        H1, m1 = ctx.homography(kp1[q1, :2], map_xy[t1], 0.1, seed=b)
+        assert (H1 is not None) == bool(found[b])
+        if H1 is not None:
+            assert np.array_equal(H1, H[b]) and np.array_equal(m1.ravel(), mask[goff[b]:goff[b + 1]])
+    assert found.sum() >= 3
+
+
+def test_batch_limits(ctx, scene):
+    _, frames = scene
+    dev = torch.device("cuda", 0)
+    t = torch.from_numpy(frames[0]).to(dev)
+    with pytest.raises(im.ImatchError):
+        ctx.sift_extract_batch_dev(t.data_ptr(), 65, 240 * 320, 240, 320, 320)
+    with pytest.raises(im.ImatchError):
+        ctx.sift_extract_batch_dev(t.data_ptr(), 2, 100, 240, 320, 320)
+    # empty segments
+    gq, gt, gd, goff = ctx.ratio_batch_dev(0, [0, 0, 0], 0.7)
+    assert goff.tolist() == [0, 0, 0]
+    H, mask, found = ctx.homography_batch(np.zeros((3, 2)), np.zeros((3, 2)), [0, 3], 0.1)
+    assert not found.any()
