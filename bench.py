@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--map-side", type=int, default=8192)
     ap.add_argument("--frames", type=int, default=16, help="distinct synthetic frames per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="frames per step and GPU, taken through the batched entry points (one launch per stage for "
+                         "the whole batch, one kNN launch over all frames' keypoints); 1 = the single-frame calls")
     ap.add_argument("--streams", type=int, default=1,
                     help="frames in flight per GPU: each has its own context (stream + arena) and host thread; a step is "
                          "then one frame per stream")
@@ -170,7 +173,53 @@ def main():
                 stats["found"] += H is not None
         return H
 
+    # batched steps: B frames resident as one [B,480,640] tensor per step
+    B = max(1, args.batch)
+    if B > 1 and (world > 1 or n_streams > 1):
+        log("note: --batch applies to single-GPU, single-stream runs; using 1")
+        B = 1
+    if B > 1:
+        n_sets = max(2, (len(frames_h) + B - 1) // B)
+        batches_d = [torch.from_numpy(np.stack([frames_h[(j * B + k) % len(frames_h)] for k in range(B)])).to(dev)
+                     for j in range(n_sets)]
+        out4_b = torch.empty((B * q_cap, 4), dtype=torch.int32, device=dev)
+
+    def step_batch(i, record=False):
+        fr = batches_d[i % len(batches_d)]
+        f, offs = ctx.sift_extract_batch_dev(fr.data_ptr(), B, 480 * 640, 480, 640, 640, params)
+        nq = len(f)
+        pyr_ms = ctx.sift_pyramid_ms() if record else 0.0
+        if nq > B * q_cap:
+            raise RuntimeError('batch has %d keypoints, buffers hold %d' % (nq, B * q_cap))
+        ctx.knn2_dev(f, f_shard, out4_b.data_ptr(), lo)
+        gq, gt, gd, goff = ctx.ratio_batch_dev(out4_b.data_ptr(), offs, ratio)
+        knn_ms = ctx.knn2_kernel_ms() if record else 0.0
+        kp = f.download(descriptors=False)[0]
+        ng = np.diff(goff)
+        use = ng > 10                                      # position_finder.py:316
+        src = kp[np.repeat(offs[:-1], ng) + gq, :2]
+        src_off = goff.copy()
+        if not use.all():                                  # frames below the gate take no part
+            keep = np.repeat(use, ng)
+            src, gt_u = src[keep], gt[keep]
+            src_off = np.concatenate([[0], np.cumsum(np.where(use, ng, 0))])
+        else:
+            gt_u = gt
+        H, _, found = ctx.homography_batch(src, map_xy[gt_u], src_off, 0.1, seeds=np.arange(B) + i * B)
+        f.free()
+        if record:
+            stats["pyr_ms"].append(pyr_ms)
+            stats["knn_ms"].append(knn_ms)
+            stats["kp"].append(nq)
+            stats["good"].append(float(ng.mean()))
+            stats["found"] += int(found.sum())
+        return H
+
     def run_steps(n, record):
+        if B > 1:
+            for i in range(n):
+                step_batch(i, record)
+            return
         if n_streams == 1:
             for i in range(n):
                 step(i, record)
@@ -211,11 +260,11 @@ def main():
         wall = float(tw.item())
 
     if rank == 0:
-        fps = world * n_streams * args.steps / wall
+        fps = world * n_streams * B * args.steps / wall
         q_mean = float(np.mean(stats["kp"]))
         knn_ms = float(np.mean(stats["knn_ms"]))
         n_local = hi - lo
-        q_per_launch = (world * q_cap) if world > 1 else q_mean
+        q_per_launch = (world * q_cap) if world > 1 else q_mean      # at --batch B: all B frames' keypoints
         flops = 256.0 * q_per_launch * n_local            # 256 flop per (query, train) pair
         achieved_tf = flops / (knn_ms * 1e-3) / 1e12
         pyr_bytes = PYRAMID_BYTES_PER_INPUT_PIXEL * args.map_side * args.map_side
@@ -226,9 +275,10 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "640x480 gray frame vs full %dx%d synthetic orthomap, %d map descriptors resident "
                                    "in HBM (configs[1])" % (args.map_side, args.map_side, n_map),
-                       "frame": "640x480 u8", "map_descriptors": n_map, "keypoints_per_frame": q_mean,
+                       "frame": "640x480 u8", "map_descriptors": n_map, "keypoints_per_frame": q_mean / B,
+                       "frames_per_step_per_gpu": B * n_streams,
                        "good_matches_per_frame": float(np.mean(stats["good"])),
-                       "homographies_found": "%d/%d" % (stats["found"], args.steps), "ratio": ratio,
+                       "homographies_found": "%d/%d" % (stats["found"], args.steps * B * n_streams), "ratio": ratio,
                        "frames_in_flight_per_gpu": n_streams,
                        "parallelism": "map sharded x%d, frames data-parallel" % world if world > 1 else "single GPU"},
             "knn_gdist_per_s": world * q_mean * n_map / (knn_ms * 1e-3) / 1e9 if world == 1

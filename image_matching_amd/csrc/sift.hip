@@ -23,6 +23,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
+#include <thread>
 #include <vector>
 
 #define MAX_OCT 16
@@ -1486,30 +1487,44 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         SegTab seg;
         memset(&seg, 0, sizeof(seg));
         seg.n = batch;
-        std::vector<KpRec> kps;
+        std::vector<int> K_of((size_t)batch, 0);
+        auto finish_image = [&](int b, std::vector<KpRec>& kps) {
+            KpRec* rec = h_kp + (size_t)b * kp_hint;
+            if (n_kp[b] <= 0) return;
+            kps.resize((size_t)n_kp[b]);
+            sort_keypoints(rec, n_kp[b], kps.data());
+            size_t j = 0;
+            for (size_t i = 1; i < kps.size(); ++i) {
+                const KpRec &a = kps[j], &c = kps[i];
+                if (a.x != c.x || a.y != c.y || a.size != c.size || a.angle != c.angle) kps[++j] = kps[i];
+            }
+            const int K = (int)j + 1;
+            const float scale = 1.f / (float)(1 << -first_octave);
+            for (int i = 0; i < K; ++i) {
+                KpRec& k = kps[i];
+                k.octave = (k.octave & ~255) | ((k.octave + first_octave) & 255);
+                k.x *= scale; k.y *= scale; k.size *= scale;
+            }
+            memcpy(rec, kps.data(), (size_t)K * sizeof(KpRec));
+            K_of[b] = K;
+        };
+        if (batch >= 4) {  // the images' lists are independent: sort them on as many host threads (at most 16)
+            const int nt = std::min(batch, 16);
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nt; ++t)
+                pool.emplace_back([&, t]() {
+                    std::vector<KpRec> kps;
+                    for (int b = t; b < batch; b += nt) finish_image(b, kps);
+                });
+            for (auto& th : pool) th.join();
+        } else {
+            std::vector<KpRec> kps;
+            for (int b = 0; b < batch; ++b) finish_image(b, kps);
+        }
         int max_k = 0;
         for (int b = 0; b < batch; ++b) {
-            KpRec* rec = h_kp + (size_t)b * kp_hint;
-            int K = 0;
-            if (n_kp[b] > 0) {
-                kps.resize((size_t)n_kp[b]);
-                sort_keypoints(rec, n_kp[b], kps.data());
-                size_t j = 0;
-                for (size_t i = 1; i < kps.size(); ++i) {
-                    const KpRec &a = kps[j], &c = kps[i];
-                    if (a.x != c.x || a.y != c.y || a.size != c.size || a.angle != c.angle) kps[++j] = kps[i];
-                }
-                K = (int)j + 1;
-                const float scale = 1.f / (float)(1 << -first_octave);
-                for (int i = 0; i < K; ++i) {
-                    KpRec& k = kps[i];
-                    k.octave = (k.octave & ~255) | ((k.octave + first_octave) & 255);
-                    k.x *= scale; k.y *= scale; k.size *= scale;
-                }
-                memcpy(rec, kps.data(), (size_t)K * sizeof(KpRec));
-            }
-            seg.off[b + 1] = seg.off[b] + K;
-            max_k = std::max(max_k, K);
+            seg.off[b + 1] = seg.off[b] + K_of[b];
+            max_k = std::max(max_k, K_of[b]);
         }
         const int Ktot = seg.off[batch];
         imatch_features* f = nullptr;
