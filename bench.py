@@ -6,12 +6,16 @@ Metric (BASELINE.json): frames/sec of the full chain CLAHE -> SIFT -> kNN(k=2)+r
 reference's map.png is not in its tree, so the "full map" is the seeded synthetic 8192x8192 orthomap of
 SURVEY.md 8d). Gdist/s of the kNN stage is reported beside it.
 
-A step = every rank takes ONE frame (already in HBM) through extract -> match against the whole map ->
-ratio -> homography. At N > 1 the map's descriptors are sharded over the ranks (contiguous index ranges),
-each rank extracts its OWN frame, queries are all-gathered, every rank matches all frames against its
-shard, and an all_to_all returns the per-shard top-2 to the frame's owner (image_matching_amd/sharded.py).
-Per-GPU work per step is constant (one extraction + Q x N_map distances), total frames per step = N:
-"scaling": "weak". value = N * steps / wall time, wall = max over ranks between two barriers.
+A step = every rank takes ONE BATCH of --batch frames (default 16, already in HBM as one [B,480,640] tensor)
+through the batched entry points: extract (every kernel launched once for the batch) -> one kNN launch
+over all the batch's keypoints against the whole map -> ratio -> homography per frame (iff > 10 good
+matches, position_finder.py:316). Per frame the results are identical to the single-frame entry points
+(tests/test_batch_gpu.py); --batch 1 runs those instead, and their latency is reported beside the
+headline as "single_frame". At N > 1 the map's descriptors are sharded over the ranks (contiguous index
+ranges), each rank extracts its OWN batch, queries are all-gathered, every rank matches all batches
+against its shard, and an all_to_all returns the per-shard top-2 to the batch's owner
+(image_matching_amd/sharded.py). Per-GPU work per step is constant, total frames per step = N * batch:
+"scaling": "weak". value = N * batch * steps / wall time, wall = max over ranks between two barriers.
 
 One JSON line on stdout (rank 0). Progress goes to stderr."""
 import argparse
@@ -70,7 +74,7 @@ def main():
     ap.add_argument("--map-side", type=int, default=8192)
     ap.add_argument("--frames", type=int, default=16, help="distinct synthetic frames per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=1,
+    ap.add_argument("--batch", type=int, default=16,
                     help="frames per step and GPU, taken through the batched entry points (one launch per stage for "
                          "the whole batch, one kNN launch over all frames' keypoints); 1 = the single-frame calls")
     ap.add_argument("--streams", type=int, default=1,
@@ -132,7 +136,7 @@ def main():
     # ---- frames: each rank has its own set, resident in HBM before the timed region
     frames_h = [synth.synth_frame(map_img, 100 * rank + i, size=(480, 640))[0] for i in range(args.frames)]
     frames_d = [torch.from_numpy(f).to(dev) for f in frames_h]
-    q_cap = 8192
+    q_cap = 4096                     # rows per frame in the exchange / result buffers (frames here have ~3000 keypoints)
 
     stats = {"kp": [], "good": [], "found": 0, "knn_ms": [], "pyr_ms": []}
 
@@ -175,36 +179,35 @@ def main():
 
     # batched steps: B frames resident as one [B,480,640] tensor per step
     B = max(1, args.batch)
-    if B > 1 and (world > 1 or n_streams > 1):
-        log("note: --batch applies to single-GPU, single-stream runs; using 1")
-        B = 1
+    if B > 1 and n_streams > 1:
+        log("note: --batch and --streams are alternatives; using --batch")
+        n_streams = 1
+    bq_cap = ((B * 3584 + 1023) // 1024) * 1024      # rows per batch in the exchange / result buffers
     if B > 1:
         n_sets = max(2, (len(frames_h) + B - 1) // B)
         batches_d = [torch.from_numpy(np.stack([frames_h[(j * B + k) % len(frames_h)] for k in range(B)])).to(dev)
                      for j in range(n_sets)]
-        out4_b = torch.empty((B * q_cap, 4), dtype=torch.int32, device=dev)
 
     def step_batch(i, record=False):
         fr = batches_d[i % len(batches_d)]
         f, offs = ctx.sift_extract_batch_dev(fr.data_ptr(), B, 480 * 640, 480, 640, 640, params)
         nq = len(f)
         pyr_ms = ctx.sift_pyramid_ms() if record else 0.0
-        if nq > B * q_cap:
-            raise RuntimeError('batch has %d keypoints, buffers hold %d' % (nq, B * q_cap))
-        ctx.knn2_dev(f, f_shard, out4_b.data_ptr(), lo)
-        gq, gt, gd, goff = ctx.ratio_batch_dev(out4_b.data_ptr(), offs, ratio)
+        if nq > bq_cap:
+            raise RuntimeError('batch has %d keypoints, buffers hold %d' % (nq, bq_cap))
+        out4 = matcher.match_dp(f, nq, bq_cap)
+        gq, gt, gd, goff = ctx.ratio_batch_dev(out4.data_ptr(), offs, ratio)
         knn_ms = ctx.knn2_kernel_ms() if record else 0.0
         kp = f.download(descriptors=False)[0]
         ng = np.diff(goff)
         use = ng > 10                                      # position_finder.py:316
         src = kp[np.repeat(offs[:-1], ng) + gq, :2]
-        src_off = goff.copy()
+        src_off = goff
+        gt_u = gt
         if not use.all():                                  # frames below the gate take no part
             keep = np.repeat(use, ng)
             src, gt_u = src[keep], gt[keep]
             src_off = np.concatenate([[0], np.cumsum(np.where(use, ng, 0))])
-        else:
-            gt_u = gt
         H, _, found = ctx.homography_batch(src, map_xy[gt_u], src_off, 0.1, seeds=np.arange(B) + i * B)
         f.free()
         if record:
@@ -259,12 +262,25 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
 
+    # single-frame latency, outside the timed region: the per-frame calls, one frame at a time
+    single_ms = None
+    if world == 1:
+        for i in range(5):
+            step(i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(20):
+            step(i)
+        barrier()
+        single_ms = (time.perf_counter() - t1) / 20 * 1e3
+
     if rank == 0:
         fps = world * n_streams * B * args.steps / wall
         q_mean = float(np.mean(stats["kp"]))
         knn_ms = float(np.mean(stats["knn_ms"]))
         n_local = hi - lo
-        q_per_launch = (world * q_cap) if world > 1 else q_mean      # at --batch B: all B frames' keypoints
+        cap_rows = bq_cap if B > 1 else q_cap
+        q_per_launch = (world * cap_rows) if world > 1 else q_mean    # one launch holds all B frames' keypoints
         flops = 256.0 * q_per_launch * n_local            # 256 flop per (query, train) pair
         achieved_tf = flops / (knn_ms * 1e-3) / 1e12
         pyr_bytes = PYRAMID_BYTES_PER_INPUT_PIXEL * args.map_side * args.map_side
@@ -277,12 +293,14 @@ def main():
                                    "in HBM (configs[1])" % (args.map_side, args.map_side, n_map),
                        "frame": "640x480 u8", "map_descriptors": n_map, "keypoints_per_frame": q_mean / B,
                        "frames_per_step_per_gpu": B * n_streams,
+                       "entry_points": "batched (imatch_sift_extract_batch_dev, one kNN launch, imatch_ratio_batch_dev, "
+                                       "imatch_homography_batch)" if B > 1 else "single-frame",
                        "good_matches_per_frame": float(np.mean(stats["good"])),
                        "homographies_found": "%d/%d" % (stats["found"], args.steps * B * n_streams), "ratio": ratio,
                        "frames_in_flight_per_gpu": n_streams,
                        "parallelism": "map sharded x%d, frames data-parallel" % world if world > 1 else "single GPU"},
             "knn_gdist_per_s": world * q_mean * n_map / (knn_ms * 1e-3) / 1e9 if world == 1
-                               else world * q_cap * float(n_local) * world / (knn_ms * 1e-3) / 1e9,
+                               else world * cap_rows * float(n_local) * world / (knn_ms * 1e-3) / 1e9,
             "roofline": {"kernel": "knn2_kernel (bf16 MFMA, fused top-2)", "bound": "mfma", "achieved": achieved_tf,
                          "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_BF16_PEAK_TF,
                          "traffic": None, "launch_ms": knn_ms,
@@ -294,6 +312,10 @@ def main():
                                  "frac": pyr_bytes / (pyr_ms_map * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                  "stage_ms": pyr_ms_map, "frame_stage_ms": float(np.mean(stats["pyr_ms"]))},
         }
+        if single_ms is not None:
+            out["single_frame"] = {"ms_per_frame": single_ms, "frames_per_s": 1e3 / single_ms,
+                                   "note": "one frame at a time through the single-frame entry points, measured after "
+                                           "the timed region; not part of value"}
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
             n_s = min(n_map, 100_000)
