@@ -78,9 +78,9 @@ __device__ __forceinline__ float max16(const f32x16& a) {
 // with acc = q.t - |t|^2/2 = -v/2 where v = |t|^2 - 2 q.t (exact: every partial sum is a multiple of
 // 1/2 below 2^23). A result can enter the query's top-2 only if v <= T, T = an upper bound of the
 // query's final second-best, i.e. acc >= G = -T/2: the hot epilogue is a 16-way max (v_max3 tree) and
-// ONE compare per block; the insertion path is wave-uniform and rare, and works on LDS (the block's
-// accumulators are parked in a scratch slot, the query's running top-2 lives in LDS), so the hot loop
-// carries only G in registers. T is shared chip-wide: every wave publishes its second-best with
+// ONE compare per block; the insertion path is wave-uniform and rare: it fetches the query's running
+// top-2 from LDS, folds the block's 16 accumulator registers into it with branch-free selects and puts
+// it back, so the hot loop carries only G in registers. T is shared chip-wide: every wave publishes its second-best with
 // atomicMin into gthr[query] once per stage and fetches the minimum back (asynchronously, into LDS),
 // so short train chunks do not keep loose thresholds. The chain of block u+1 is issued before the
 // epilogue of block u (two accumulator sets), so the VALU work hides under the MFMAs.
@@ -95,14 +95,13 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
     constexpr int NT = TN / 32;                  // 32-row tiles per stage
     constexpr int ST_F = QB * 256;               // floats of top-2 state per wave: [QB][b1,b2,i1,i2][64]
     constexpr int TH_F = 3 * QB * 64;            // floats of fetched thresholds per wave: [3][QB][64]
-    __shared__ uint4 lds[2 * STAGE_U4 + (4 * ST_F + 4 * 1024 + 4 * TH_F) / 4];
+    __shared__ uint4 lds[2 * STAGE_U4 + (4 * ST_F + 4 * TH_F) / 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     float* const extra = (float*)(lds + 2 * STAGE_U4);
     float* const st = extra + wave * ST_F;
-    float* const scratch = extra + 4 * ST_F + wave * 1024;
-    float* const thl = extra + 4 * ST_F + 4 * 1024 + wave * TH_F;
+    float* const thl = extra + 4 * ST_F + wave * TH_F;
 
     // workgroups b and b+8 share an XCD (its L2): same train chunk, different query tiles
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -225,25 +224,24 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
         // strict <: OpenCV's lowest-index tie-break.
         auto epilogue = [&](const f32x16& a, int qb, int tile) {
             if (__builtin_amdgcn_ballot_w64(max16(a) >= G[qb])) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) scratch[reg * 64 + lane] = a[reg];
                 float* sq = st + qb * 256;
                 float b1 = sq[lane], b2 = sq[64 + lane];
                 int i1 = __float_as_int(sq[128 + lane]), i2 = __float_as_int(sq[192 + lane]);
                 const int rowbase = s * TN + tile * 32 + 4 * h;
                 const float g = G[qb];
-#pragma unroll 1
+                // all 16 results straight from the accumulator registers, branch-free selects
+#pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const float v = scratch[reg * 64 + lane];
-                    if (v >= g) {
-                        const float x = -2.0f * v;
-                        const int idx = rowbase + (reg & 3) + 8 * (reg >> 2);
-                        if (x < b1) {
-                            b2 = b1; i2 = i1; b1 = x; i1 = idx;
-                        } else if (x < b2) {
-                            b2 = x; i2 = idx;
-                        }
-                    }
+                    const float v = a[reg];
+                    const float x = -2.0f * v;
+                    const int idx = rowbase + (reg & 3) + 8 * (reg >> 2);
+                    const bool pass = v >= g;
+                    const bool lt1 = pass && x < b1;
+                    const bool lt2 = pass && !lt1 && x < b2;
+                    b2 = lt1 ? b1 : (lt2 ? x : b2);
+                    i2 = lt1 ? i1 : (lt2 ? idx : i2);
+                    b1 = lt1 ? x : b1;
+                    i1 = lt1 ? idx : i1;
                 }
                 sq[lane] = b1; sq[64 + lane] = b2;
                 sq[128 + lane] = __int_as_float(i1); sq[192 + lane] = __int_as_float(i2);
@@ -549,9 +547,13 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     const int nStages = (int)(t->n_pad / TNs);
     // chunks: a multiple of 8 (one group per XCD); about two workgroups per CU slot; >= 4 stages per chunk
     const int slots = 512;
-    int nChunks = (2 * slots + nQt - 1) / nQt;
-    if (nChunks > nStages / 4) nChunks = nStages / 4;
-    nChunks = (nChunks / 8) * 8;
+    // (rounded DOWN to a multiple of 8, so that the grid stays within two rounds of slots)
+    int nChunks = ((2 * slots + nQt - 1) / nQt / 8) * 8;
+    // ... and chunks of at most 16k rows (4 MB, one XCD's L2): the query tiles that share a chunk then
+    // re-read it from L2 however far apart they run, and the many short workgroups balance the tail
+    nChunks = std::max(nChunks, (int)((t->n_pad + 16383) / 16384 + 7) / 8 * 8);
+    nChunks = std::min(nChunks, 256);
+    if (nChunks > nStages / 4) nChunks = (nStages / 4 / 8) * 8;
     if (nChunks < 8) nChunks = 8;
     if (const char* e = getenv("IMATCH_KNN_CHUNKS")) nChunks = std::max(8, atoi(e) / 8 * 8);  // tuning override
     const int64_t nLists = (int64_t)nChunks * 2;
