@@ -312,6 +312,16 @@ def main():
                                  "frac": pyr_bytes / (pyr_ms_map * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                  "stage_ms": pyr_ms_map, "frame_stage_ms": float(np.mean(stats["pyr_ms"]))},
         }
+        # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes over this same command
+        # (profiles/r1_pmc.md); it is attached only when that measurement was taken on the same launch shape
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_knn.json")) as fh:
+                pmc = json.load(fh)
+            if world == 1 and B == 32 and abs(pmc.get("n_queries", q_mean) - q_mean) < 0.05 * q_mean:
+                out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE, " + pmc["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         if single_ms is not None:
             out["single_frame"] = {"ms_per_frame": single_ms, "frames_per_s": 1e3 / single_ms,
                                    "note": "one frame at a time through the single-frame entry points, measured after "
