@@ -179,25 +179,23 @@ def main():
 
     # batched steps: B frames resident as one [B,480,640] tensor per step
     B = max(1, args.batch)
-    if B > 1 and n_streams > 1:
-        log("note: --batch and --streams are alternatives; using --batch")
-        n_streams = 1
     bq_cap = ((B * 3584 + 1023) // 1024) * 1024      # rows per batch in the exchange / result buffers
     if B > 1:
         n_sets = max(2, (len(frames_h) + B - 1) // B)
         batches_d = [torch.from_numpy(np.stack([frames_h[(j * B + k) % len(frames_h)] for k in range(B)])).to(dev)
                      for j in range(n_sets)]
 
-    def step_batch(i, record=False):
-        fr = batches_d[i % len(batches_d)]
-        f, offs = ctx.sift_extract_batch_dev(fr.data_ptr(), B, 480 * 640, 480, 640, 640, params)
+    def step_batch(i, record=False, lane=0):
+        cx, mt = ctxs[lane], matchers[lane]
+        fr = batches_d[(i * n_streams + lane) % len(batches_d)]
+        f, offs = cx.sift_extract_batch_dev(fr.data_ptr(), B, 480 * 640, 480, 640, 640, params)
         nq = len(f)
-        pyr_ms = ctx.sift_pyramid_ms() if record else 0.0
+        pyr_ms = cx.sift_pyramid_ms() if record else 0.0
         if nq > bq_cap:
             raise RuntimeError('batch has %d keypoints, buffers hold %d' % (nq, bq_cap))
-        out4 = matcher.match_dp(f, nq, bq_cap)
-        gq, gt, gd, goff = ctx.ratio_batch_dev(out4.data_ptr(), offs, ratio)
-        knn_ms = ctx.knn2_kernel_ms() if record else 0.0
+        out4 = mt.match_dp(f, nq, bq_cap)
+        gq, gt, gd, goff = cx.ratio_batch_dev(out4.data_ptr(), offs, ratio)
+        knn_ms = cx.knn2_kernel_ms() if record else 0.0
         kp = f.download(descriptors=False)[0]
         ng = np.diff(goff)
         use = ng > 10                                      # position_finder.py:316
@@ -208,31 +206,29 @@ def main():
             keep = np.repeat(use, ng)
             src, gt_u = src[keep], gt[keep]
             src_off = np.concatenate([[0], np.cumsum(np.where(use, ng, 0))])
-        H, _, found = ctx.homography_batch(src, map_xy[gt_u], src_off, 0.1, seeds=np.arange(B) + i * B)
+        H, _, found = cx.homography_batch(src, map_xy[gt_u], src_off, 0.1, seeds=np.arange(B) + i * B)
         f.free()
         if record:
-            stats["pyr_ms"].append(pyr_ms)
-            stats["knn_ms"].append(knn_ms)
-            stats["kp"].append(nq)
-            stats["good"].append(float(ng.mean()))
-            stats["found"] += int(found.sum())
+            with stats_lock:
+                stats["pyr_ms"].append(pyr_ms)
+                stats["knn_ms"].append(knn_ms)
+                stats["kp"].append(nq)
+                stats["good"].append(float(ng.mean()))
+                stats["found"] += int(found.sum())
         return H
 
     def run_steps(n, record):
-        if B > 1:
-            for i in range(n):
-                step_batch(i, record)
-            return
+        one = step_batch if B > 1 else step
         if n_streams == 1:
             for i in range(n):
-                step(i, record)
+                one(i, record)
             return
         errs = []
 
         def worker(lane):
             try:
                 for i in range(n):
-                    step(i, record, lane)
+                    one(i, record, lane)
             except Exception as e:      # surfaced after the join
                 errs.append(e)
         ts = [threading.Thread(target=worker, args=(l,)) for l in range(n_streams)]

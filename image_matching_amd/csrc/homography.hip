@@ -7,6 +7,8 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 #define HOMO_HYPOTHESES 4096
@@ -240,10 +242,10 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
     unsigned long long* h_key = (unsigned long long*)((char*)ctx->hs + dbytes + fbytes);  // pinned: no staging copy
     HIP_TRY(ctx, hipMemcpyAsync(h_key, d_best, kbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int b = 0; b < nseg; ++b) {
+    auto finish = [&](int b) {
         const int n = seg.off[b + 1] - seg.off[b];
         const unsigned long long key = h_key[b];
-        if (n < 4 || key == 0) continue;  // no non-degenerate sample
+        if (n < 4 || key == 0) return;  // no non-degenerate sample
         const double* P = Pall + 4 * (size_t)seg.off[b];
         const float* sp = src + 2 * (size_t)seg.off[b];
         const float* dp = dst + 2 * (size_t)seg.off[b];
@@ -251,17 +253,17 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
         const double* td = &Td[3 * b];
         const uint32_t h = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
         double Hb[9];
-        if (!hypothesis(P, n, seeds[b], h, Hb) || fabs(Hb[8]) <= 1e-9) continue;
+        if (!hypothesis(P, n, seeds[b], h, Hb) || fabs(Hb[8]) <= 1e-9) return;
         double h8[8];
         for (int k = 0; k < 8; ++k) h8[k] = Hb[k] / Hb[8];
-        if (!refit(P, n, tau[b] * tau[b], h8)) continue;
+        if (!refit(P, n, tau[b] * tau[b], h8)) return;
         const double Hn[9] = {h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7], 1.0};
         const double TS[9] = {ts[0], 0, -ts[0] * ts[1], 0, ts[0], -ts[0] * ts[2], 0, 0, 1};
         const double TDi[9] = {1.0 / td[0], 0, td[1], 0, 1.0 / td[0], td[2], 0, 0, 1};
         double t[9], H[9];
         mul3(Hn, TS, t);
         mul3(TDi, t, H);
-        if (fabs(H[8]) < 1e-12) continue;
+        if (fabs(H[8]) < 1e-12) return;
         double* Ho = H_out + 9 * (size_t)b;
         for (int k = 0; k < 9; ++k) Ho[k] = H[k] / H[8];
         if (mask)
@@ -273,6 +275,15 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
                 mask[seg.off[b] + i] = (ex * ex + ey * ey <= thr * thr) ? 1 : 0;
             }
         found[b] = 1;
+    };
+    if (nseg >= 4) {  // the problems are independent: refit them on host threads (at most 16)
+        const int nt = std::min(nseg, 16);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t)
+            pool.emplace_back([&, t]() { for (int b = t; b < nseg; b += nt) finish(b); });
+        for (auto& th : pool) th.join();
+    } else {
+        for (int b = 0; b < nseg; ++b) finish(b);
     }
     return IMATCH_OK;
 }
