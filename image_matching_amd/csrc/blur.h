@@ -1,0 +1,282 @@
+// GaussianBlur for the SIFT scale space on gfx950 (device code shared by sift.hip and tools/blur_bench.hip).
+//
+// blur_march_kernel: a workgroup owns a strip of W output columns and MARCHES down it in chunks of 32
+// rows. Per chunk it (1) writes the 32 new input rows (prefetched into registers during the previous
+// chunk's arithmetic) to LDS as interleaved row pairs, (2) runs the row pass on them -- two rows per
+// v_pk_fma_f32 -- into a 64-row ring of row-pass results, (3) runs the column pass for the 32 output
+// rows whose taps are now all in the ring. Compared with one tile per workgroup this never re-reads or
+// recomputes the vertical halo (2R of 32+2R rows), keeps the next chunk's HBM loads in flight behind the
+// current chunk's arithmetic, and all 256 threads have exactly one row-pass item and one column-pass item
+// per chunk. Each output is still one ascending-tap fma chain per pass: bit-identical to the scalar form
+// the CPU oracle computes (oracle/sift_oracle.c, GaussianBlur of sift.dispatch.cpp's pyramid).
+//
+// UP = true reads the u8 image and forms createInitialImage's x2 INTER_LINEAR value on the fly (the 2x
+// f32 base is never stored). With u8 sources every product and sum of that interpolation is exact in
+// f32, and clamped source indices reproduce OpenCV's border rule exactly, so any evaluation order gives
+// the oracle's bits.
+//
+// dec != nullptr also writes the next octave's layer 0 (every second pixel of this output).
+//
+// The grid is one-dimensional and XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs, so
+// id -> (id % 8) * per + id / 8 makes the workgroups that are resident together on one XCD neighbouring
+// strips, whose shared halo columns then hit that XCD's L2 instead of HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+template <int R>
+struct GK { float k[2 * R + 1]; };
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (p < 0) p = -p;                       // one fold each way covers every halo narrower than the image
+    if (p >= len) p = 2 * (len - 1) - p;
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+// value (dy, dx) of the x2 INTER_LINEAR upsample of a u8 image of urows x ucols
+__device__ __forceinline__ float upsample2_value(const uint8_t* __restrict__ s, int urows, int ucols, int ustride, int dy,
+                                                 int dx) {
+    const int i = dx >> 1, j = dy >> 1;
+    int xa, xb, ya, yb;
+    float wxa, wya;
+    if (dx & 1) { xa = i; xb = min(i + 1, ucols - 1); wxa = 0.75f; } else { xa = max(i - 1, 0); xb = i; wxa = 0.25f; }
+    if (dy & 1) { ya = j; yb = min(j + 1, urows - 1); wya = 0.75f; } else { ya = max(j - 1, 0); yb = j; wya = 0.25f; }
+    const uint8_t* s0 = s + (size_t)ya * ustride;
+    const uint8_t* s1 = s + (size_t)yb * ustride;
+    const float h0 = s0[xa] * wxa + s0[xb] * (1.f - wxa);
+    const float h1 = s1[xa] * wxa + s1[xb] * (1.f - wxa);
+    return h0 * wya + h1 * (1.f - wya);
+}
+
+#define BM_CH 32  // rows per chunk
+
+template <int R, int W, bool UP>
+__global__ void __launch_bounds__(256, (W == 64 ? 4 : 2))
+blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float* __restrict__ dec, int rows, int cols,
+                  int ustride, GK<R> gk, int nt, int nstrip, int nseg, size_t src_zs, size_t zs) {
+    static_assert(R >= 1 && R <= 16, "the 64-row ring holds 32 + 2R rows");
+    static_assert(W == 64 || W == 128, "strip width");
+    constexpr int N = 2 * R + 1, CH = BM_CH, NP = CH / 2;
+    constexpr int XO = (R + 3) & ~3, P = W + 2 * XO, NX4 = P / 4;
+    constexpr int NITEM = NP * NX4, NIT = (NITEM + 255) / 256;
+    __shared__ float in[NP * P * 2];
+    __shared__ float ring[64 * W];
+
+    const int tid = threadIdx.x;
+    int strip, seg;
+    {
+        const int total = nstrip * nseg, per = (total + 7) >> 3;
+        const int id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (id >= total) return;
+        seg = id / nstrip;
+        strip = id - seg * nstrip;
+    }
+    const float* srcf = UP ? nullptr : (const float*)((const char*)src_ + (size_t)blockIdx.z * src_zs);
+    const uint8_t* srcu = UP ? (const uint8_t*)src_ + (size_t)blockIdx.z * src_zs : nullptr;
+    dst = (float*)((char*)dst + (size_t)blockIdx.z * zs);
+    if (dec) dec = (float*)((char*)dec + (size_t)blockIdx.z * zs);
+    const int urows = rows >> 1, ucols = cols >> 1;   // UP: the u8 image
+    const int x0 = strip * W, y_start = seg * CH * nt, y_end = min(rows, y_start + CH * nt);
+    const int xl = x0 - XO;                          // image column of LDS column 0
+    const bool colfast = xl >= 0 && xl + P <= cols && (UP || (cols & 3) == 0);
+
+    // ---- chunk input: rows [yin, yin + 2 * np) -> registers (fast path) ...
+    float4 pa[NIT], pb[NIT];
+    // UP: the chunk's first row has the parity of R (y_start and the chunk height are even), so a row pair
+    // needs u8 rows j-1, j, j+1 (even first row 2j) or j, j+1 (odd first row 2j+1); the raw bytes wait in
+    // registers and are interpolated when they land.
+    constexpr int UPR = (R & 1) ? 2 : 3;
+    unsigned ub[NIT][UPR][4];
+    auto issue = [&](int yin, int np) {
+        if (UP) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int item = min(tid + it * 256, np * NX4 - 1);
+                const int yp = item / NX4, x4 = item - yp * NX4;
+                const int j = (yin + 2 * yp) >> 1, i0 = (xl + 4 * x4) >> 1;   // xl + 4*x4 is a multiple of 4
+                const int c[4] = {max(i0 - 1, 0), i0, i0 + 1, min(i0 + 2, ucols - 1)};
+#pragma unroll
+                for (int q = 0; q < UPR; ++q) {
+                    const int sr = (R & 1) ? min(j + q, urows - 1) : min(max(j - 1 + q, 0), urows - 1);
+                    const uint8_t* sp = srcu + (size_t)sr * ustride;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) ub[it][q][cc] = sp[c[cc]];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int item = min(tid + it * 256, np * NX4 - 1);
+                const int yp = item / NX4, x4 = item - yp * NX4;
+                const float* g = srcf + (size_t)(yin + 2 * yp) * cols + (xl + 4 * x4);
+                pa[it] = *(const float4*)g;
+                pb[it] = *(const float4*)(g + cols);
+            }
+        }
+    };
+    // ... -> LDS, element (row 2*yp + par, col) at ((yp * P + col) * 2 + par)
+    auto land = [&](int np) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (UP) {
+                float h[UPR][4];
+#pragma unroll
+                for (int q = 0; q < UPR; ++q) {
+                    const float s0 = (float)ub[it][q][0], s1 = (float)ub[it][q][1], s2 = (float)ub[it][q][2],
+                                s3 = (float)ub[it][q][3];
+                    h[q][0] = s0 * 0.25f + s1 * 0.75f;
+                    h[q][1] = s1 * 0.75f + s2 * 0.25f;
+                    h[q][2] = s1 * 0.25f + s2 * 0.75f;
+                    h[q][3] = s2 * 0.75f + s3 * 0.25f;
+                }
+                float r0[4], r1[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    if (R & 1) {   // rows 2j+1, 2j+2
+                        r0[cc] = h[0][cc] * 0.75f + h[1][cc] * 0.25f;
+                        r1[cc] = h[0][cc] * 0.25f + h[1][cc] * 0.75f;
+                    } else {       // rows 2j, 2j+1
+                        r0[cc] = h[0][cc] * 0.25f + h[1][cc] * 0.75f;
+                        r1[cc] = h[1][cc] * 0.75f + h[UPR - 1][cc] * 0.25f;
+                    }
+                }
+                pa[it] = make_float4(r0[0], r0[1], r0[2], r0[3]);
+                pb[it] = make_float4(r1[0], r1[1], r1[2], r1[3]);
+            }
+            const int item = tid + it * 256;
+            if (item < np * NX4) {
+                const int yp = item / NX4, x4 = item - yp * NX4;
+                float4* l = (float4*)&in[(yp * P + 4 * x4) * 2];
+                l[0] = make_float4(pa[it].x, pb[it].x, pa[it].y, pb[it].y);
+                l[1] = make_float4(pa[it].z, pb[it].z, pa[it].w, pb[it].w);
+            }
+        }
+    };
+    // border chunks and border strips: element-wise through reflect-101, loads batched before the LDS writes
+    auto fill_slow = [&](int yin, int np) {
+        constexpr int NE = (2 * NP * P + 255) / 256;
+        float e[NE];
+        const int ne = 2 * np * P;
+#pragma unroll
+        for (int it = 0; it < NE; ++it) {
+            const int f = min(tid + it * 256, ne - 1);
+            const int yp = f / (2 * P), rem = f - yp * (2 * P);
+            const int gy = reflect101(yin + 2 * yp + (rem & 1), rows), gx = reflect101(xl + (rem >> 1), cols);
+            e[it] = UP ? upsample2_value(srcu, urows, ucols, ustride, gy, gx) : srcf[(size_t)gy * cols + gx];
+        }
+#pragma unroll
+        for (int it = 0; it < NE; ++it) {
+            const int f = tid + it * 256;
+            if (f < ne) in[f] = e[it];
+        }
+    };
+    auto chunk_fast = [&](int yin, int np) { return colfast && yin >= 0 && yin + 2 * np <= rows; };
+
+    // row pass over np row pairs of `in`; results go to ring rows (rel0 + 2*yp, +1) & 63
+    auto row_pass = [&](int np, int rel0) {
+        constexpr int E0 = (XO - R) & ~1, E1 = (XO + R + 4 + 1) & ~1, OFF = XO - R - E0;
+        for (int item = tid; item < np * (W / 4); item += 256) {
+            const int yp = item / (W / 4), xq = (item - yp * (W / 4)) * 4;
+            f2 v[E1 - E0];
+#pragma unroll
+            for (int i = 0; i < (E1 - E0) / 2; ++i) {
+                const float4 q = *(const float4*)&in[(yp * P + xq + E0 + 2 * i) * 2];
+                v[2 * i] = f2{q.x, q.y};
+                v[2 * i + 1] = f2{q.z, q.w};
+            }
+            f2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+            for (int t = 0; t < N; ++t) {
+                const f2 k = {gk.k[t], gk.k[t]};
+                a0 = __builtin_elementwise_fma(k, v[OFF + t], a0);
+                a1 = __builtin_elementwise_fma(k, v[OFF + t + 1], a1);
+                a2 = __builtin_elementwise_fma(k, v[OFF + t + 2], a2);
+                a3 = __builtin_elementwise_fma(k, v[OFF + t + 3], a3);
+            }
+            const int rr = rel0 + 2 * yp;
+            *(float4*)&ring[(rr & 63) * W + xq] = make_float4(a0.x, a1.x, a2.x, a3.x);
+            *(float4*)&ring[((rr + 1) & 63) * W + xq] = make_float4(a0.y, a1.y, a2.y, a3.y);
+        }
+    };
+
+    // ---- prologue: ring rows rel 0 .. 2R-1 = image rows y_start - R .. y_start + R - 1
+    {
+        const int yin = y_start - R;
+        if (chunk_fast(yin, R)) { issue(yin, R); land(R); } else fill_slow(yin, R);
+        __syncthreads();
+        row_pass(R, 0);
+        __syncthreads();
+    }
+    const int nchunk = (y_end - y_start + CH - 1) / CH;
+    bool have = false;   // registers hold the next chunk's rows
+    {
+        const int yin = y_start + R;
+        if (chunk_fast(yin, NP)) { issue(yin, NP); have = true; }
+    }
+    for (int s = 0; s < nchunk; ++s) {
+        const int yin = y_start + R + CH * s;
+        // everyone is past the previous row pass (barrier below it), so `in` is free; the barrier after
+        // this fill also orders the previous column pass's ring reads before the next row pass's ring writes
+        if (have) land(NP); else fill_slow(yin, NP);
+        have = false;
+        if (s + 1 < nchunk && chunk_fast(yin + CH, NP)) { issue(yin + CH, NP); have = true; }
+        __syncthreads();
+        row_pass(NP, 2 * R + CH * s);
+        __syncthreads();
+        // column pass: thread = 2 adjacent columns x 4 output rows
+        for (int item = tid; item < (W / 2) * (CH / 4); item += 256) {
+            const int cp = item % (W / 2), r4 = (item / (W / 2)) * 4;
+            f2 v[4 + 2 * R];
+#pragma unroll
+            for (int i = 0; i < 4 + 2 * R; ++i) v[i] = *(const f2*)&ring[((CH * s + r4 + i) & 63) * W + 2 * cp];
+            f2 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f2{0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < N; ++t) {
+                const f2 k = {gk.k[t], gk.k[t]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_elementwise_fma(k, v[t + j], acc[j]);
+            }
+            const int gx = x0 + 2 * cp;
+            const bool pair_ok = ((cols & 1) == 0) && gx + 1 < cols;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gy = y_start + CH * s + r4 + j;
+                if (gy >= y_end || gx >= cols) continue;
+                const size_t o = (size_t)gy * cols + gx;
+                if (pair_ok) {
+                    *(f2*)&dst[o] = acc[j];
+                } else {
+                    dst[o] = acc[j].x;
+                    if (gx + 1 < cols) dst[o + 1] = acc[j].y;
+                }
+                if (dec && !(j & 1) && (gy >> 1) < (rows >> 1) && (gx >> 1) < (cols >> 1))
+                    dec[(size_t)(gy >> 1) * (cols >> 1) + (gx >> 1)] = acc[j].x;
+            }
+        }
+    }
+}
+
+// Host launcher. nt = chunks of 32 rows a workgroup marches through (0: chosen here so that the launch
+// still has several workgroups per CU slot).
+template <int R, int W, bool UP>
+static inline void blur_march_launch(hipStream_t st, const void* src, float* dst, float* dec, int rows, int cols, int ustride,
+                                     const float* k, int batch, size_t src_zs, size_t zs, int nt = 0) {
+    GK<R> gk;
+    for (int i = 0; i < 2 * R + 1; ++i) gk.k[i] = k[i];
+    const int nstrip = (cols + W - 1) / W, nchunk = (rows + BM_CH - 1) / BM_CH;
+    if (nt <= 0) {
+        // at least ~8 workgroups per CU (256 CUs) before the march gets longer; at most 16 chunks
+        nt = 16;
+        while (nt > 1 && (long long)nstrip * ((nchunk + nt - 1) / nt) * batch < 2048) nt >>= 1;
+    }
+    const int nseg = (nchunk + nt - 1) / nt, total = nstrip * nseg;
+    hipLaunchKernelGGL((blur_march_kernel<R, W, UP>), dim3((unsigned)((total + 7) & ~7), 1, (unsigned)batch), dim3(256), 0, st,
+                       src, dst, dec, rows, cols, ustride, gk, nt, nstrip, nseg, src_zs, zs);
+}

@@ -3,13 +3,14 @@
 //
 // Stages (all f32, the arithmetic order follows OpenCV's sift.simd.hpp so that the pyramid is
 // bit-identical to the CPU oracle; -ffp-contract=off, every fma below is explicit):
-//   upsample2   u8 -> f32, x2 bilinear (createInitialImage)
-//   blur<R>     separable Gaussian, one 64x64 tile per workgroup staged through LDS with its
-//               halo; row pass and column pass use register sliding windows; the DoG layer
-//               (output - input) is written by the same kernel, so each pyramid layer is read
-//               once and written once
-//   decimate    next octave's layer 0 = every second pixel of layer nOctaveLayers
-//   detect      26-neighbour extremum scan over the DoG triplets -> candidate list (atomic append)
+//   blur<R>     separable Gaussian, blur.h: a workgroup marches down a 64-column strip, 32 rows at a
+//               time, through LDS; the base blur forms the x2 bilinear upsample of the u8 image on the
+//               fly (createInitialImage) and the blur of layer nOctaveLayers also writes the next
+//               octave's layer 0 (every second pixel), so each Gaussian layer is read once and
+//               written once and nothing else of the scale space is stored
+//   detect      26-neighbour extremum scan; the DoG layers are never materialised: every consumer
+//               (scan, refinement) forms gauss[i+1] - gauss[i] from the two Gaussian layers, the
+//               same single f32 subtraction the oracle stores -> candidate list (atomic append)
 //   refine      adjustLocalExtrema: <=5 Newton steps (3x3 Cramer solve), contrast and edge tests
 //   orient      one wavefront per keypoint: 36-bin gradient histogram, smoothing, peaks
 //   (host)      KeyPointsFilter::removeDuplicatedSorted order + first-octave rescale
@@ -18,6 +19,7 @@
 // so results do not depend on the order in which lanes arrive.
 #include "common.h"
 #include "preproc.h"
+#include "blur.h"
 #include <algorithm>
 #include <float.h>
 #include <limits.h>
@@ -36,7 +38,6 @@
 
 struct PyrTable {
     float* gauss[MAX_OCT][MAX_LAY];
-    float* dog[MAX_OCT][MAX_LAY];
     int rows[MAX_OCT], cols[MAX_OCT];
     int n_oct, nl;
 };
@@ -45,7 +46,6 @@ struct PyrTable {
 // every kernel is launched with gridDim.z = batch size. ZP shifts a frame-0 pointer to this block's frame.
 #define ZP(p) ((decltype(p))((char*)(p) + zo))
 #define TG(o, i) ((float*)((char*)T.gauss[o][i] + zo))
-#define TD(o, i) ((float*)((char*)T.dog[o][i] + zo))
 typedef imatch_segtab SegTab;   // rows of image b: [off[b], off[b+1])
 
 struct RefinedKp {   // output of refine, input of orient
@@ -84,15 +84,6 @@ void imatch_sift_state_free(imatch_ctx* ctx) {
     ctx->sift = nullptr;
 }
 
-__device__ __forceinline__ int reflect101(int p, int len) {
-    if (p < 0) p = -p;                       // one fold each way covers every halo narrower than the image
-    if (p >= len) p = 2 * (len - 1) - p;
-    if ((unsigned)p < (unsigned)len) return p;
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
-    return p;
-}
-
 // ---- createInitialImage: u8 -> f32, x2 INTER_LINEAR ------------------------------------------
 __global__ void __launch_bounds__(256)
 upsample2_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, float* __restrict__ dst, size_t src_zs,
@@ -121,149 +112,10 @@ upsample2_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride
     dst[(size_t)dy * (2 * cols) + dx] = h0 * (1.f - fy) + h1 * fy;
 }
 
-// ---- GaussianBlur (+ DoG) ---------------------------------------------------------------------
-template <int R>
-struct GK { float k[2 * R + 1]; };
-
+// ---- GaussianBlur ------------------------------------------------------------------------------------
+// The templated radii run blur_march_kernel (blur.h).
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
-
-// One 64x32 output tile per workgroup (4 workgroups share a CU, so one tile's loads overlap the
-// others' arithmetic). Tile fill goes through registers: 16-byte global loads of rows y and y+1 (all
-// of a thread's loads are issued before its first LDS write), written to LDS as interleaved row
-// pairs -- element (y, x) at ((y/2)*P + x)*2 + (y&1) -- so that one 16-byte LDS read yields
-// (y,x) (y+1,x) (y,x+1) (y+1,x+1) and the row pass works on two rows per instruction (v_pk_fma_f32).
-// The column pass packs two adjacent columns per thread the same way. Each output is still one
-// ascending-tap fma chain: bit-identical to the scalar form the CPU oracle computes.
-// (Measured alternatives, tools/blur_bench.hip: 4-byte LDS-DMA fill is instruction-rate bound at
-// ~1.6 TB/s; a lane-per-row/lane-per-column variant with padded pitches was slower for R <= 10.)
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-template <int R>
-__global__ void __launch_bounds__(256, 4)
-blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int rows, int cols, GK<R> gk,
-            size_t zs) {
-    {
-        const size_t zo = (size_t)blockIdx.z * zs;
-        src = ZP(src); dst = ZP(dst);
-        if (dog) dog = ZP(dog);
-    }
-    constexpr int N = 2 * R + 1, TH = 32, H2 = TH + 2 * R;      // H2 is even
-    constexpr int XO = (R + 3) & ~3, P = 64 + 2 * XO;            // x origin of the tile = x0 - XO; P % 8 == 0
-    constexpr int NX4 = P / 4, NITEM = (H2 / 2) * NX4;           // one item = 4 columns of a row pair
-    __shared__ float lds[H2 * P + H2 * 64];
-    float* in = lds;
-    float* tmp = lds + H2 * P;
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TH;
-    // Tiles that touch the image border, or images whose rows are not 16-byte multiples, are filled
-    // element-wise with the reflect-101 mapping.
-    const bool interior = (cols & 3) == 0 && x0 - XO >= 0 && x0 - XO + P <= cols && y0 - R >= 0 && y0 - R + H2 <= rows;
-    if (interior) {
-        constexpr int NIT = (NITEM + 255) / 256;
-        float4 a[NIT], b[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int item = min(tid + it * 256, NITEM - 1);
-            const int yp = item / NX4, x4 = item - yp * NX4;
-            const float* g = src + (size_t)(y0 - R + 2 * yp) * cols + (x0 - XO + 4 * x4);
-            a[it] = *(const float4*)g;
-            b[it] = *(const float4*)(g + cols);
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int item = tid + it * 256;
-            if (item < NITEM) {
-                const int yp = item / NX4, x4 = item - yp * NX4;
-                float4* l = (float4*)&in[(yp * P + 4 * x4) * 2];
-                l[0] = make_float4(a[it].x, b[it].x, a[it].y, b[it].y);
-                l[1] = make_float4(a[it].z, b[it].z, a[it].w, b[it].w);
-            }
-        }
-    } else {
-        // all of a thread's loads are issued before its first LDS write here too: on a camera frame the
-        // border tiles are what the launch waits for
-        constexpr int NE = (H2 * P + 255) / 256;
-        float e[NE];
-#pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            const int f = min(tid + it * 256, H2 * P - 1);
-            const int yp = f / (2 * P), rem = f - yp * (2 * P);
-            const int col = rem >> 1, row = 2 * yp + (rem & 1);
-            e[it] = src[(size_t)reflect101(y0 - R + row, rows) * cols + reflect101(x0 - XO + col, cols)];
-        }
-#pragma unroll
-        for (int it = 0; it < NE; ++it) {
-            const int f = tid + it * 256;
-            if (f < H2 * P) in[f] = e[it];
-        }
-    }
-    __syncthreads();
-    // row pass: one item = a row pair x 4 consecutive outputs; taps in ascending order
-    {
-        constexpr int E0 = (XO - R) & ~1, E1 = (XO + R + 4 + 1) & ~1, OFF = XO - R - E0;
-        for (int item = tid; item < (H2 / 2) * 16; item += 256) {
-            const int yp = item >> 4, xq = (item & 15) * 4;
-            f2 v[E1 - E0];
-#pragma unroll
-            for (int i = 0; i < (E1 - E0) / 2; ++i) {
-                const float4 q = *(const float4*)&in[(yp * P + xq + E0 + 2 * i) * 2];
-                v[2 * i] = f2{q.x, q.y};
-                v[2 * i + 1] = f2{q.z, q.w};
-            }
-            f2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-#pragma unroll
-            for (int t = 0; t < N; ++t) {
-                const f2 k = {gk.k[t], gk.k[t]};
-                a0 = __builtin_elementwise_fma(k, v[OFF + t], a0);
-                a1 = __builtin_elementwise_fma(k, v[OFF + t + 1], a1);
-                a2 = __builtin_elementwise_fma(k, v[OFF + t + 2], a2);
-                a3 = __builtin_elementwise_fma(k, v[OFF + t + 3], a3);
-            }
-            *(float4*)&tmp[(2 * yp) * 64 + xq] = make_float4(a0.x, a1.x, a2.x, a3.x);
-            *(float4*)&tmp[(2 * yp + 1) * 64 + xq] = make_float4(a0.y, a1.y, a2.y, a3.y);
-        }
-    }
-    __syncthreads();
-    // column pass: thread = 2 adjacent columns x 4 output rows
-    {
-        const int cp = tid & 31, r4 = (tid >> 5) * 4;
-        f2 v[4 + 2 * R];
-#pragma unroll
-        for (int i = 0; i < 4 + 2 * R; ++i) v[i] = *(const f2*)&tmp[(r4 + i) * 64 + 2 * cp];
-        f2 acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = f2{0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < N; ++t) {
-            const f2 k = {gk.k[t], gk.k[t]};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_elementwise_fma(k, v[t + j], acc[j]);
-        }
-        const int gx = x0 + 2 * cp;
-        const bool pair_ok = ((cols & 1) == 0) && gx + 1 < cols;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gy = y0 + r4 + j;
-            if (gy >= rows || gx >= cols) continue;
-            const int yy = r4 + j + R;
-            const float c0 = in[((yy >> 1) * P + 2 * cp + XO) * 2 + (yy & 1)];
-            const float c1 = in[((yy >> 1) * P + 2 * cp + 1 + XO) * 2 + (yy & 1)];
-            const size_t o = (size_t)gy * cols + gx;
-            if (pair_ok) {
-                *(f2*)&dst[o] = acc[j];
-                if (dog) *(f2*)&dog[o] = f2{acc[j].x - c0, acc[j].y - c1};
-            } else {
-                dst[o] = acc[j].x;
-                if (dog) dog[o] = acc[j].x - c0;
-                if (gx + 1 < cols) {
-                    dst[o + 1] = acc[j].y;
-                    if (dog) dog[o + 1] = acc[j].y - c1;
-                }
-            }
-        }
-    }
-}
 
 // any other radius (non-default sigma / nOctaveLayers): plain per-tap loops, same arithmetic order
 #define RT_MAXR 20
@@ -282,17 +134,14 @@ blur_rows_rt_kernel(const float* __restrict__ src, float* __restrict__ tmp, int 
 }
 
 __global__ void __launch_bounds__(256)
-blur_cols_rt_kernel(const float* __restrict__ tmp, const float* __restrict__ src, float* __restrict__ dst,
-                    float* __restrict__ dog, int rows, int cols, GKrt gk, size_t zs) {
+blur_cols_rt_kernel(const float* __restrict__ tmp, float* __restrict__ dst, int rows, int cols, GKrt gk, size_t zs) {
     const size_t zo = (size_t)blockIdx.z * zs;
-    tmp = ZP(tmp); src = ZP(src); dst = ZP(dst);
-    if (dog) dog = ZP(dog);
+    tmp = ZP(tmp); dst = ZP(dst);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
     float acc = 0.f;
     for (int t = 0; t < 2 * gk.r + 1; ++t) acc = fmaf(gk.k[t], tmp[(size_t)reflect101(y + t - gk.r, rows) * cols + x], acc);
     dst[(size_t)y * cols + x] = acc;
-    if (dog) dog[(size_t)y * cols + x] = acc - src[(size_t)y * cols + x];
 }
 
 __global__ void __launch_bounds__(256)
@@ -361,9 +210,9 @@ __device__ __forceinline__ void stage_flush_block(const Rec* stage, int n_staged
 }
 
 // ---- findScaleSpaceExtrema: candidate scan ------------------------------------------------------
-// Tile of 64x16 pixels per workgroup; the (nl+2) DoG layers of the tile with a 1-pixel halo are
-// brought into LDS with asynchronous loads (each DoG pixel is read from HBM once), then every thread
-// tests 4 rows x nl layers.
+// Tile of 64x16 pixels per workgroup; the (nl+3) Gaussian layers of the tile with a 1-pixel halo are
+// brought into LDS with asynchronous loads (each pixel is read from HBM once) and differenced in
+// place into the nl+2 DoG layers, then every thread tests 4 rows x nl layers.
 #define DT_W 64
 #define DT_H 16
 #define DT_PITCH 68
@@ -373,10 +222,10 @@ __global__ void __launch_bounds__(256)
 detect_kernel_generic(PyrTable T, int o, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count, size_t zs) {
     const size_t zo = (size_t)blockIdx.z * zs;
     cand = ZP(cand); count = ZP(count);
-    __shared__ float lds[(MAX_LAY - 1) * DT_LAYER + 64];
+    __shared__ float lds[MAX_LAY * DT_LAYER + 64];
     __shared__ uint2 stage_all[4][DET_STAGE];
     __shared__ int wcnt[5];
-    const int cols = T.cols[o], rows = T.rows[o], nlay = T.nl + 2;
+    const int cols = T.cols[o], rows = T.rows[o], nlay = T.nl + 3;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * DT_W + SIFT_IMG_BORDER, y0 = blockIdx.y * DT_H + SIFT_IMG_BORDER;
@@ -386,10 +235,19 @@ detect_kernel_generic(PyrTable T, int o, float thr, uint2* __restrict__ cand, in
         const int l = f / DT_LAYER, rem = f - l * DT_LAYER;
         const int row = rem / DT_PITCH, col = rem - row * DT_PITCH;
         const int gy = min(max(y0 - 1 + row, 0), rows - 1), gx = min(max(x0 - 1 + col, 0), cols - 1);
-        const float* g = TD(o, l) + (size_t)gy * cols + gx;
+        const float* g = TG(o, l) + (size_t)gy * cols + gx;
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lds + piece * 64), 4, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int e = tid; e < DT_LAYER; e += 256) {   // a thread owns its elements through all layers
+        float lo = lds[e];
+        for (int l = 0; l + 1 < nlay; ++l) {
+            const float hi = lds[(l + 1) * DT_LAYER + e];
+            lds[l * DT_LAYER + e] = hi - lo;
+            lo = hi;
+        }
+    }
     __syncthreads();
     const int c = x0 + lane;
     const bool col_ok = c < cols - SIFT_IMG_BORDER;
@@ -425,10 +283,11 @@ detect_kernel_generic(PyrTable T, int o, float thr, uint2* __restrict__ cand, in
     stage_flush_block(stage, n_staged, wcnt, cand, cap, count);
 }
 
-// nOctaveLayers = 3 (5 DoG layers), the default: a streaming scan with no LDS and no barrier. A wave
+// nOctaveLayers = 3 (6 Gaussian -> 5 DoG layers), the default: a streaming scan with no LDS and no barrier. A wave
 // owns a strip of 62 output columns (lanes 0 and 63 carry the halo columns) and walks `rpw` output rows
 // (32 on a map: 6% halo re-reads; 8 on a camera frame, where the walk's serial load latency is the cost);
-// per row and layer it loads ONE value per lane (a coalesced 256-byte row segment), gets the left and
+// per row and Gaussian layer it loads ONE value per lane (a coalesced 256-byte row segment), differences
+// adjacent layers into the DoG values, gets the left and
 // right neighbours from the adjacent lanes, and keeps a 3-row window of horizontal max/min in
 // registers. Instead of 26 compares per pixel and layer, every layer's 3x3 max and min are built
 // separably and shared by the three layers that need them: val is a maximum iff
@@ -449,16 +308,19 @@ detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ 
     int n_staged = 0;
     const bool wave_active = ry0 < rows - SIFT_IMG_BORDER;  // wave-uniform
     const int xc = min(max(x, 0), cols - 1);
-    const float* p[5];
+    const float* p[6];
 #pragma unroll
-    for (int l = 0; l < 5; ++l) p[l] = TD(o, l) + xc;
+    for (int l = 0; l < 6; ++l) p[l] = TG(o, l) + xc;
     const bool col_ok = lane >= 1 && lane <= DS_COLS && x < cols - SIFT_IMG_BORDER;
     float hm[5][3], hn[5][3], cv[3][3];
     auto load_row = [&](int row, int slot) {
         const size_t off = (size_t)min(row, rows - 1) * cols;
+        float g[6];
+#pragma unroll
+        for (int l = 0; l < 6; ++l) g[l] = p[l][off];
 #pragma unroll
         for (int l = 0; l < 5; ++l) {
-            const float v = p[l][off];
+            const float v = g[l + 1] - g[l];
             const float a = __shfl_up(v, 1), d = __shfl_down(v, 1);
             hm[l][slot] = fmaxf(fmaxf(a, v), d);
             hn[l][slot] = fminf(fminf(a, v), d);
@@ -499,7 +361,7 @@ detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ 
 // From the first octave of at most TAIL_MAXPX pixels on (60x80 for a 640x480 frame) a launch per layer
 // is all latency: 7 launches per octave for a few thousand pixels. One 1024-thread workgroup instead
 // walks those octaves start to finish: the current Gaussian layer, the row-pass intermediate and a
-// ring of three DoG layers live in LDS; every layer is also written to the global pyramid (refine,
+// ring of three DoG layers live in LDS; every Gaussian layer is also written to the global pyramid (refine,
 // orientation and descriptors read it there). Same ascending-tap fma chains, same reflect-101, same
 // extremum predicate as the per-layer kernels, so the result is bit-identical to them.
 #define TAIL_MAXPX 4800
@@ -559,7 +421,6 @@ pyramid_tail_kernel(PyrTable T, int o_start, TailK gk, float thr, uint2* __restr
             __syncthreads();  // also: every detect below has finished reading the ring slot rewritten next
             float* dslot = dg + ((i - 1) % 3) * TAIL_MAXPX;
             float* gout = TG(o, i);
-            float* dout = TD(o, i - 1);
             for (int p = tid; p < n; p += 1024) {
                 const int y = p / cols, x = p - y * cols;
                 float acc = 0.f;
@@ -568,7 +429,6 @@ pyramid_tail_kernel(PyrTable T, int o_start, TailK gk, float thr, uint2* __restr
                 gout[p] = acc;
                 const float dv = acc - src[p];
                 dslot[p] = dv;
-                dout[p] = dv;
                 if (i == nl && has_next && !(y & 1) && !(x & 1) && (y >> 1) < nrows2 && (x >> 1) < ncols2)
                     nx[(y >> 1) * ncols2 + (x >> 1)] = acc;
             }
@@ -663,7 +523,7 @@ __device__ __forceinline__ void tf_row_pass(const float* __restrict__ A, float* 
 template <int R>
 __device__ __forceinline__ void tf_col_pass(float* __restrict__ A, const float* __restrict__ tm, const float* k, int rows,
                                             int cols, int P, float* __restrict__ ring, float* __restrict__ gout,
-                                            float* __restrict__ dout, float* __restrict__ nx) {
+                                            float* __restrict__ nx) {
     constexpr int N = 2 * R + 1;
     const int items = ((rows + 3) >> 2) * cols;
     const int ncols2 = cols >> 1, nrows2 = rows >> 1;
@@ -691,7 +551,6 @@ __device__ __forceinline__ void tf_col_pass(float* __restrict__ A, const float* 
             const int p = y * cols + x;
             ring[p] = dv;
             gout[p] = acc[jj];
-            dout[p] = dv;
             if (nx && !(y & 1) && !(x & 1) && (y >> 1) < nrows2 && (x >> 1) < ncols2) nx[(y >> 1) * ncols2 + (x >> 1)] = acc[jj];
         }
     }
@@ -780,8 +639,7 @@ pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* _
 #define TF_LAYER(I, R, NX)                                                                                         \
         tf_row_pass<R>(A, tm, gk.k[I - 1], rows, cols, P);                                                         \
         __syncthreads(); /* also: the scan before this is done with the ring slot rewritten next */              \
-        tf_col_pass<R>(A, tm, gk.k[I - 1], rows, cols, P, dg + ((I - 1) % 3) * TAIL_MAXPX, TG(o, I),         \
-                       TD(o, I - 1), NX);                                                                       \
+        tf_col_pass<R>(A, tm, gk.k[I - 1], rows, cols, P, dg + ((I - 1) % 3) * TAIL_MAXPX, TG(o, I), NX);     \
         __syncthreads();                                                                                           \
         if (I < 5) { tf_mirror(A, rows, cols, P); __syncthreads(); }
         TF_LAYER(1, R1, nullptr)
@@ -821,11 +679,10 @@ __device__ __forceinline__ bool refine_one(const PyrTable& T, const size_t zo, c
                 cross_deriv_scale = img_scale * 0.25f;
     float xi = 0, xr = 0, xc = 0;
     int i = 0;
-#define AT(p, rr, cc) (p)[(size_t)(rr) * cols + (cc)]
+    // DoG layer l = gauss[l+1] - gauss[l], formed here; img/prev/next name DoG layers by their index
+#define AT(l, rr, cc) (TG(octv, (l) + 1)[(size_t)(rr) * cols + (cc)] - TG(octv, (l))[(size_t)(rr) * cols + (cc)])
     for (; i < SIFT_MAX_INTERP_STEPS; i++) {
-        const float* img = TD(octv, layer);
-        const float* prev = TD(octv, layer - 1);
-        const float* next = TD(octv, layer + 1);
+        const int img = layer, prev = layer - 1, next = layer + 1;
         const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
                              (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
                              (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
@@ -850,9 +707,7 @@ __device__ __forceinline__ bool refine_one(const PyrTable& T, const size_t zo, c
     if (i >= SIFT_MAX_INTERP_STEPS) return false;
     float contr;
     {
-        const float* img = TD(octv, layer);
-        const float* prev = TD(octv, layer - 1);
-        const float* next = TD(octv, layer + 1);
+        const int img = layer, prev = layer - 1, next = layer + 1;
         const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
                              (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
                              (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
@@ -1131,39 +986,47 @@ static int gauss_kernel(double sigma, float* k, int maxn) {
     return n;
 }
 
-template <int R>
-static void launch_blur_fixed(hipStream_t st, const float* src, float* dst, float* dog, int rows, int cols, const float* k,
-                              int batch, size_t zs) {
-    GK<R> gk;
-    memcpy(gk.k, k, sizeof(gk.k));
-    hipLaunchKernelGGL(blur_kernel<R>, dim3((cols + 63) / 64, (rows + 31) / 32, batch), dim3(256), 0, st, src, dst, dog,
-                       rows, cols, gk, zs);
-}
-
-// GaussianBlur(src, dst, Size(), sigma) [+ dog = dst - src]; tmp: scratch of the same size (runtime-radius path)
+// GaussianBlur(src, dst, Size(), sigma). The templated radii take the marching kernel, which can also
+//   - read the u8 image and upsample it on the fly (up_u8 != nullptr: src is ignored, rows x cols is the x2 size),
+//   - write the next octave's layer 0 (dec != nullptr);
+// other radii (non-default sigma / nOctaveLayers) run per-tap kernels through `tmp`; asked for either
+// extra they set *fused = false, and the caller launches upsample / decimate itself.
 static bool blur_radius_is_templated(int r) { return r == 4 || r == 5 || r == 6 || r == 8 || r == 10 || r == 13; }
 
-static int gaussian_blur(imatch_ctx* ctx, hipStream_t st, const float* src, float* dst, float* dog, float* tmp, int rows,
-                         int cols, double sigma, int batch, size_t zs) {
+template <int R>
+static void launch_blur_fixed(hipStream_t st, const float* src, const uint8_t* up_u8, int ustride, size_t src_zs, float* dst,
+                              float* dec, int rows, int cols, const float* k, int batch, size_t zs) {
+    if (up_u8) blur_march_launch<R, 64, true>(st, up_u8, dst, dec, rows, cols, ustride, k, batch, src_zs, zs);
+    else blur_march_launch<R, 64, false>(st, src, dst, dec, rows, cols, 0, k, batch, zs, zs);
+}
+
+static int gaussian_blur(imatch_ctx* ctx, hipStream_t st, const float* src, const uint8_t* up_u8, int ustride, size_t src_zs,
+                         float* dst, float* dec, float* tmp, int rows, int cols, double sigma, int batch, size_t zs,
+                         bool* fused) {
     float k[2 * RT_MAXR + 1];
     const int n = gauss_kernel(sigma, k, 2 * RT_MAXR + 1);
     if (n < 0) return imatch_set_err(ctx, IMATCH_ESIZE, "Gaussian sigma %g needs a kernel wider than %d", sigma, 2 * RT_MAXR + 1);
     const int r = n / 2;
+    if (fused) *fused = true;
     switch (r) {
-        case 4: launch_blur_fixed<4>(st, src, dst, dog, rows, cols, k, batch, zs); break;
-        case 5: launch_blur_fixed<5>(st, src, dst, dog, rows, cols, k, batch, zs); break;
-        case 6: launch_blur_fixed<6>(st, src, dst, dog, rows, cols, k, batch, zs); break;
-        case 8: launch_blur_fixed<8>(st, src, dst, dog, rows, cols, k, batch, zs); break;
-        case 10: launch_blur_fixed<10>(st, src, dst, dog, rows, cols, k, batch, zs); break;
-        case 13: launch_blur_fixed<13>(st, src, dst, dog, rows, cols, k, batch, zs); break;
+        case 4: launch_blur_fixed<4>(st, src, up_u8, ustride, src_zs, dst, dec, rows, cols, k, batch, zs); break;
+        case 5: launch_blur_fixed<5>(st, src, up_u8, ustride, src_zs, dst, dec, rows, cols, k, batch, zs); break;
+        case 6: launch_blur_fixed<6>(st, src, up_u8, ustride, src_zs, dst, dec, rows, cols, k, batch, zs); break;
+        case 8: launch_blur_fixed<8>(st, src, up_u8, ustride, src_zs, dst, dec, rows, cols, k, batch, zs); break;
+        case 10: launch_blur_fixed<10>(st, src, up_u8, ustride, src_zs, dst, dec, rows, cols, k, batch, zs); break;
+        case 13: launch_blur_fixed<13>(st, src, up_u8, ustride, src_zs, dst, dec, rows, cols, k, batch, zs); break;
         default: {
+            if (up_u8 || dec) {
+                if (!fused) return imatch_set_err(ctx, IMATCH_EINVAL, "internal: fused blur needs a templated radius");
+                *fused = false;
+                if (up_u8) return IMATCH_OK;   // the caller materialises the x2 image and calls again with src
+            }
             GKrt gk;
             gk.r = r;
             memcpy(gk.k, k, sizeof(float) * n);
             const dim3 grid((cols + 63) / 64, (rows + 3) / 4, batch);
             hipLaunchKernelGGL(blur_rows_rt_kernel, grid, dim3(256), 0, st, src, tmp, rows, cols, gk, zs);
-            hipLaunchKernelGGL(blur_cols_rt_kernel, grid, dim3(256), 0, st, (const float*)tmp, src, dst, dog, rows,
-                               cols, gk, zs);
+            hipLaunchKernelGGL(blur_cols_rt_kernel, grid, dim3(256), 0, st, (const float*)tmp, dst, rows, cols, gk, zs);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1260,15 +1123,36 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     const size_t o_img = take((size_t)h * w), o_clahe = take((size_t)h * w);
     const size_t o_cscr = take((size_t)(P->clahe ? P->clahe_tiles_x * P->clahe_tiles_y : 1) * 1280);
-    const size_t o_up = take((size_t)brows * bcols * 4), o_tmp = take((size_t)brows * bcols * 4);
-    size_t o_g[MAX_OCT][MAX_LAY], o_d[MAX_OCT][MAX_LAY];
+    // the x2 f32 image and the row-pass scratch exist only on the runtime-radius path
+    double sig[MAX_LAY];
+    sig[0] = P->sigma;
+    {
+        const double kf = pow(2., 1. / nl);
+        for (int i = 1; i < nl + 3; i++) {
+            const double sig_prev = pow(kf, (double)(i - 1)) * P->sigma, sig_total = sig_prev * kf;
+            sig[i] = sqrt(sig_total * sig_total - sig_prev * sig_prev);
+        }
+    }
+    const float sig_diff = sqrtf(fmaxf((float)P->sigma * (float)P->sigma - 0.5f * 0.5f * 4, 0.01f));
+    bool all_templated = true;
+    {
+        float kk[2 * RT_MAXR + 1];
+        int n = gauss_kernel(sig_diff, kk, 2 * RT_MAXR + 1);
+        if (n < 0 || !blur_radius_is_templated(n / 2)) all_templated = false;
+        for (int i = 1; i < nl + 3; ++i) {
+            n = gauss_kernel(sig[i], kk, 2 * RT_MAXR + 1);
+            if (n < 0 || !blur_radius_is_templated(n / 2)) all_templated = false;
+        }
+    }
+    const size_t o_up = take(all_templated ? 0 : (size_t)brows * bcols * 4);
+    const size_t o_tmp = take(all_templated ? 0 : (size_t)brows * bcols * 4);
+    size_t o_g[MAX_OCT][MAX_LAY];
     for (int o = 0; o < n_oct; ++o) {
         T.rows[o] = o == 0 ? brows : T.rows[o - 1] / 2;
         T.cols[o] = o == 0 ? bcols : T.cols[o - 1] / 2;
         if (T.rows[o] < 1 || T.cols[o] < 1) { n_oct = o; break; }
         const size_t px = (size_t)T.rows[o] * T.cols[o] * 4;
         for (int i = 0; i < nl + 3; ++i) o_g[o][i] = take(px);
-        for (int i = 0; i < nl + 2; ++i) o_d[o][i] = take(px);
     }
     T.n_oct = n_oct;
     int cap = (int)std::min<size_t>((size_t)brows * bcols / 8 + 16384, (size_t)1 << 28);
@@ -1293,7 +1177,6 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         char* A = S->arena;
         for (int o = 0; o < n_oct; ++o) {
             for (int i = 0; i < nl + 3; ++i) T.gauss[o][i] = (float*)(A + o_g[o][i]);
-            for (int i = 0; i < nl + 2; ++i) T.dog[o][i] = (float*)(A + o_d[o][i]);
         }
         S->T = T;
         S->h = h;
@@ -1330,17 +1213,16 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if (batch == 1) HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
         else HIP_TRY(ctx, hipMemset2DAsync(d_cnt, zs, 0, 256, (size_t)batch, ctx->stream));
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
-        hipLaunchKernelGGL(upsample2_kernel, dim3((bcols + 63) / 64, (brows + 3) / 4, batch), dim3(256), 0, ctx->stream, d_src,
-                           h, w, src_stride, d_up, src_zs, zs);
-        const float sig_diff = sqrtf(fmaxf((float)P->sigma * (float)P->sigma - 0.5f * 0.5f * 4, 0.01f));
-        int rc = gaussian_blur(ctx, ctx->stream, d_up, T.gauss[0][0], nullptr, d_tmp, brows, bcols, sig_diff, batch, zs);
+        bool fused = false;
+        int rc = gaussian_blur(ctx, ctx->stream, nullptr, d_src, src_stride, src_zs, T.gauss[0][0], nullptr, d_tmp, brows, bcols,
+                               sig_diff, batch, zs, &fused);
         if (rc) return rc;
-        double sig[MAX_LAY];
-        sig[0] = P->sigma;
-        const double kf = pow(2., 1. / nl);
-        for (int i = 1; i < nl + 3; i++) {
-            const double sig_prev = pow(kf, (double)(i - 1)) * P->sigma, sig_total = sig_prev * kf;
-            sig[i] = sqrt(sig_total * sig_total - sig_prev * sig_prev);
+        if (!fused) {
+            hipLaunchKernelGGL(upsample2_kernel, dim3((bcols + 63) / 64, (brows + 3) / 4, batch), dim3(256), 0, ctx->stream,
+                               d_src, h, w, src_stride, d_up, src_zs, zs);
+            rc = gaussian_blur(ctx, ctx->stream, d_up, nullptr, 0, 0, T.gauss[0][0], nullptr, d_tmp, brows, bcols, sig_diff, batch,
+                               zs, nullptr);
+            if (rc) return rc;
         }
         const float thr = (float)(int)floor(0.5 * P->contrast_threshold / nl * 255);
         // octaves from o_tail on go to the single-workgroup kernel
@@ -1349,34 +1231,35 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // fork/join (see imatch_sift_state); the runtime-radius blur shares d_tmp, so it stays on one stream
         // An event record + cross-stream wait costs ~20 us per octave (tools/launch_bench.hip), more than a
         // camera frame's octave gains; on a map the overlap fills the tails of the big launches.
-        bool use_side = (size_t)brows * bcols * batch >= ((size_t)1 << 22);
-        for (int i = 1; i < nl + 3; ++i) {
-            float kk[2 * RT_MAXR + 1];
-            const int n = gauss_kernel(sig[i], kk, 2 * RT_MAXR + 1);
-            if (n < 0 || !blur_radius_is_templated(n / 2)) use_side = false;
-        }
+        bool use_side = all_templated && (size_t)brows * bcols * batch >= ((size_t)1 << 22);
         if (use_side && !S->side) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&S->side, hipStreamNonBlocking));
             for (int i = 0; i < MAX_OCT; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_fork[i], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming));
         }
         hipStream_t st2 = use_side ? S->side : ctx->stream;
+        bool have_l0 = true;   // layer 0 of octave o was written by the previous octave's layer-nl blur
         for (int o = 0; o < o_tail; ++o) {
             const int rows = T.rows[o], cols = T.cols[o];
-            if (o > 0)
+            if (o > 0 && !have_l0)
                 hipLaunchKernelGGL(decimate_kernel, dim3((cols + 63) / 64, (rows + 3) / 4, batch), dim3(256), 0, ctx->stream,
                                    (const float*)T.gauss[o - 1][nl], T.cols[o - 1], T.gauss[o][0], rows, cols, zs);
             for (int i = 1; i <= nl; ++i) {
-                rc = gaussian_blur(ctx, ctx->stream, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i],
-                                   batch, zs);
+                // the tail kernel decimates for itself, so only octaves that stay on this path get the fused output
+                float* dec = (i == nl && o + 1 < o_tail) ? T.gauss[o + 1][0] : nullptr;
+                bool fz = true;
+                rc = gaussian_blur(ctx, ctx->stream, T.gauss[o][i - 1], nullptr, 0, 0, T.gauss[o][i], dec, d_tmp, rows, cols, sig[i],
+                                   batch, zs, &fz);
                 if (rc) return rc;
+                if (i == nl) have_l0 = dec != nullptr && fz;
             }
             if (use_side) {
                 HIP_TRY(ctx, hipEventRecord(S->ev_fork[o], ctx->stream));
                 HIP_TRY(ctx, hipStreamWaitEvent(st2, S->ev_fork[o], 0));
             }
             for (int i = nl + 1; i < nl + 3; ++i) {
-                rc = gaussian_blur(ctx, st2, T.gauss[o][i - 1], T.gauss[o][i], T.dog[o][i - 1], d_tmp, rows, cols, sig[i], batch, zs);
+                rc = gaussian_blur(ctx, st2, T.gauss[o][i - 1], nullptr, 0, 0, T.gauss[o][i], nullptr, d_tmp, rows, cols, sig[i], batch,
+                                   zs, nullptr);
                 if (rc) return rc;
             }
             if (rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER) {
@@ -1640,9 +1523,15 @@ int imatch_sift_debug_layer(imatch_ctx* ctx, int kind, int o, int i, float* out,
     if (cols) *cols = T.cols[o];
     if (out) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
-        const float* p = kind == 0 ? T.gauss[o][i] : T.dog[o][i];
-        HIP_TRY(ctx, hipMemcpyAsync(out, p, (size_t)T.rows[o] * T.cols[o] * 4, hipMemcpyDeviceToHost, ctx->stream));
+        const size_t n = (size_t)T.rows[o] * T.cols[o];
+        HIP_TRY(ctx, hipMemcpyAsync(out, T.gauss[o][i], n * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (kind == 1) {   // DoG layers are not stored: the same f32 subtraction the kernels make
+            std::vector<float> hi(n);
+            HIP_TRY(ctx, hipMemcpyAsync(hi.data(), T.gauss[o][i + 1], n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (size_t q = 0; q < n; ++q) out[q] = hi[q] - out[q];
+        }
     }
     return IMATCH_OK;
 }

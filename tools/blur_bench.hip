@@ -1,142 +1,192 @@
-// Ablation harness for the blur kernel (tool, not product): times variants on a 16384x16384 f32 layer.
-#include <hip/hip_runtime.h>
+// Ablation / exactness harness for the marching blur kernel (tool, not product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o /tmp/blur_bench tools/blur_bench.hip
+// Checks blur_march_kernel bit-for-bit against a naive two-pass kernel (same ascending-tap fma chains) on
+// odd-sized and large images, f32 and u8-upsampled sources, with and without the decimated output, then
+// times it on a 16384x16384 layer and on a batch-like 1280x960 x 32 layer for each radius / strip / march.
+#include "../image_matching_amd/csrc/blur.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
-#define GLOBAL_AS __attribute__((address_space(1)))
-#define LDS_AS __attribute__((address_space(3)))
-template <int R> struct GK { float k[2 * R + 1]; };
-__device__ __forceinline__ int reflect101(int p, int len) {
-    if ((unsigned)p < (unsigned)len) return p;
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
-    return p;
+
+struct GKrt { int r; float k[41]; };
+__global__ void ref_rows(const float* src, float* tmp, int rows, int cols, GKrt gk) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    float acc = 0.f;
+    for (int t = 0; t < 2 * gk.r + 1; ++t) acc = fmaf(gk.k[t], src[(size_t)y * cols + reflect101(x + t - gk.r, cols)], acc);
+    tmp[(size_t)y * cols + x] = acc;
 }
-// MODE 0: full; 1: fill only; 2: fill + row pass; 3: no fill
-template <int R, int MODE>
-__global__ void __launch_bounds__(256, 4)
-blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int rows, int cols, GK<R> gk) {
-    constexpr int N = 2 * R + 1, TH = 32, H2 = TH + 2 * R;      // H2 <= 58: one lane per tile row
-    constexpr int XO = (R + 3) & ~3, P = 64 + 2 * XO;            // x origin of the tile = x0 - XO
-    constexpr int PP = P + 4, TP = 68;                           // padded pitches: (PP/4) and (TP/4) are odd
-    constexpr int NX4 = P / 4, NITEM = H2 * NX4;
-    static_assert(H2 <= 64, "row pass maps one lane to one tile row");
-    __shared__ float lds[H2 * PP + H2 * TP];
-    float* in = lds;
-    float* tmp = lds + H2 * PP;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TH;
-    // Tiles that touch the image border, or images whose rows are not 16-byte multiples, are filled
-    // element-wise with the reflect-101 mapping.
-    const bool interior = (cols & 3) == 0 && x0 - XO >= 0 && x0 - XO + P <= cols && y0 - R >= 0 && y0 - R + H2 <= rows;
-    if (MODE == 3) {} else if (interior) {
-        constexpr int NIT = (NITEM + 255) / 256;
-        float4 a[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int item = min(tid + it * 256, NITEM - 1);
-            const int row = item / NX4, x4 = item - row * NX4;
-            a[it] = *(const float4*)(src + (size_t)(y0 - R + row) * cols + (x0 - XO + 4 * x4));
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int item = tid + it * 256;
-            if (item < NITEM) {
-                const int row = item / NX4, x4 = item - row * NX4;
-                *(float4*)&in[row * PP + 4 * x4] = a[it];
-            }
-        }
-    } else {
-        for (int f = tid; f < H2 * P; f += 256) {
-            const int row = f / P, col = f - row * P;
-            in[row * PP + col] = src[(size_t)reflect101(y0 - R + row, rows) * cols + reflect101(x0 - XO + col, cols)];
-        }
-    }
-    __syncthreads();
-    if (MODE == 1) { for (int j = 0; j < 8; ++j) { size_t o = (size_t)(y0 + wv * 8 + j) * cols + x0 + lane; dst[o] = in[(wv * 8 + j) * PP + lane]; dog[o] = in[(wv * 8 + j + 1) * PP + lane]; } return; }
-    // row pass: lane = tile row, wave = group of 8 outputs (two rounds cover the 64 columns)
-    if (lane < H2) {
-        constexpr int A0 = (XO - R) & ~3, A1 = (XO + R + 8 + 3) & ~3, OFF = XO - R - A0;
-#pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
-            const int xq = (wv + 4 * rnd) * 8;
-            float v[A1 - A0];
-#pragma unroll
-            for (int i = 0; i < (A1 - A0) / 4; ++i) {
-                const float4 q = *(const float4*)&in[lane * PP + xq + A0 + 4 * i];
-                v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
-            }
-            float acc[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-            for (int t = 0; t < N; ++t) {
-                const float k = gk.k[t];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(k, v[OFF + t + j], acc[j]);
-            }
-            *(float4*)&tmp[lane * TP + xq] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            *(float4*)&tmp[lane * TP + xq + 4] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        }
-    }
-    __syncthreads();
-    if (MODE == 2) { for (int j = 0; j < 8; ++j) { size_t o = (size_t)(y0 + wv * 8 + j) * cols + x0 + lane; dst[o] = tmp[(wv * 8 + j) * TP + lane]; dog[o] = tmp[(wv * 8 + j + 1) * TP + lane]; } return; }
-    // column pass: lane = column, wave = 8 output rows
-    {
-        const int r8 = wv * 8;
-        float v[8 + 2 * R];
-#pragma unroll
-        for (int i = 0; i < 8 + 2 * R; ++i) v[i] = tmp[(r8 + i) * TP + lane];
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int t = 0; t < N; ++t) {
-            const float k = gk.k[t];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(k, v[t + j], acc[j]);
-        }
-        const int gx = x0 + lane;
-        if (gx < cols) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int gy = y0 + r8 + j;
-                if (gy < rows) {
-                    dst[(size_t)gy * cols + gx] = acc[j];
-                    if (dog) dog[(size_t)gy * cols + gx] = acc[j] - in[(r8 + j + R) * PP + lane + XO];
-                }
-            }
-        }
-    }
+__global__ void ref_cols(const float* tmp, float* dst, int rows, int cols, GKrt gk) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    float acc = 0.f;
+    for (int t = 0; t < 2 * gk.r + 1; ++t) acc = fmaf(gk.k[t], tmp[(size_t)reflect101(y + t - gk.r, rows) * cols + x], acc);
+    dst[(size_t)y * cols + x] = acc;
+}
+__global__ void ref_up(const uint8_t* src, int rows, int cols, float* dst) {   // the formula of createInitialImage
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= 2 * cols || dy >= 2 * rows) return;
+    float fx = (float)((dx + 0.5) * 0.5 - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= cols - 1) { fx = 0; sx = cols - 1; }
+    float fy = (float)((dy + 0.5) * 0.5 - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    if (sy < 0) { fy = 0; sy = 0; }
+    if (sy >= rows - 1) { fy = 0; sy = rows - 1; }
+    const int sx1 = min(sx + 1, cols - 1), sy1 = min(sy + 1, rows - 1);
+    const uint8_t* s0 = src + (size_t)sy * cols;
+    const uint8_t* s1 = src + (size_t)sy1 * cols;
+    const float a1 = fx, a0 = 1.f - a1;
+    const float h0 = s0[sx] * a0 + s0[sx1] * a1;
+    const float h1 = s1[sx] * a0 + s1[sx1] * a1;
+    dst[(size_t)dy * (2 * cols) + dx] = h0 * (1.f - fy) + h1 * fy;
+}
+__global__ void fill_f32(float* p, size_t n, unsigned seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (float)(h & 0xffff) * (255.f / 65535.f);
+}
+__global__ void fill_u8(uint8_t* p, size_t n, unsigned seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (uint8_t)(h >> 7);
+}
+__global__ void cmp_kernel(const float* a, const float* b, size_t n, unsigned long long* bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (__float_as_uint(a[i]) != __float_as_uint(b[i])) atomicAdd(bad, 1ull);
+}
+__global__ void cmp_dec(const float* full, const float* dec, int rows, int cols, unsigned long long* bad) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols / 2 || y >= rows / 2) return;
+    if (__float_as_uint(full[(size_t)(2 * y) * cols + 2 * x]) != __float_as_uint(dec[(size_t)y * (cols / 2) + x])) atomicAdd(bad, 1ull);
+}
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+
+static void gauss(int R, float* k) {   // any normalised, asymmetric-free kernel will do for the check
+    double sigma = (2 * R + 1 - 1) / 8.0, sum = 0;
+    std::vector<double> v(2 * R + 1);
+    for (int i = 0; i <= 2 * R; ++i) { v[i] = exp(-(double)(i - R) * (i - R) / (2 * sigma * sigma)); sum += v[i]; }
+    for (int i = 0; i <= 2 * R; ++i) k[i] = (float)(v[i] / sum);
 }
 
-__global__ void copy_kernel(const float4* __restrict__ a, float4* __restrict__ b, float4* __restrict__ c, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { float4 v = a[i]; b[i] = v; c[i] = v; }
+static unsigned long long* d_bad;
+static unsigned long long count_bad(const float* a, const float* b, size_t n) {
+    CK(hipMemset(d_bad, 0, 8));
+    hipLaunchKernelGGL(cmp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a, b, n, d_bad);
+    unsigned long long h;
+    CK(hipMemcpy(&h, d_bad, 8, hipMemcpyDeviceToHost));
+    return h;
 }
-template <int R, int MODE> float run(const float* s, float* d, float* g, int n) {
-    GK<R> gk; for (int i = 0; i < 2 * R + 1; ++i) gk.k[i] = 1.f / (2 * R + 1);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    dim3 grid(n / 64, n / 32);
-    hipLaunchKernelGGL((blur_kernel<R, MODE>), grid, dim3(256), 0, 0, s, d, g, n, n, gk);
-    hipEventRecord(e0);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((blur_kernel<R, MODE>), grid, dim3(256), 0, 0, s, d, g, n, n, gk);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1); return ms / 3;
+
+template <int R, int W>
+static int check(int rows, int cols, int nt, float* src, float* tmp, float* ref, float* dst, float* dec, uint8_t* u8) {
+    float k[2 * R + 1];
+    gauss(R, k);
+    GKrt g; g.r = R; memcpy(g.k, k, sizeof(k));
+    const size_t n = (size_t)rows * cols;
+    const dim3 grid((cols + 63) / 64, (rows + 3) / 4);
+    int fails = 0;
+    // f32 source (+ decimated output)
+    hipLaunchKernelGGL(fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, src, n, 77u + R);
+    hipLaunchKernelGGL(ref_rows, grid, dim3(256), 0, 0, (const float*)src, tmp, rows, cols, g);
+    hipLaunchKernelGGL(ref_cols, grid, dim3(256), 0, 0, (const float*)tmp, ref, rows, cols, g);
+    CK(hipMemset(dst, 0xff, n * 4));
+    blur_march_launch<R, W, false>(0, src, dst, dec, rows, cols, 0, k, 1, 0, 0, nt);
+    CK(hipDeviceSynchronize());
+    unsigned long long bad = count_bad(ref, dst, n);
+    CK(hipMemset(d_bad, 0, 8));
+    hipLaunchKernelGGL(cmp_dec, grid, dim3(256), 0, 0, (const float*)ref, (const float*)dec, rows, cols, d_bad);
+    unsigned long long bad_dec;
+    CK(hipMemcpy(&bad_dec, d_bad, 8, hipMemcpyDeviceToHost));
+    if (bad || bad_dec) { printf("  MISMATCH f32 R=%d W=%d %dx%d nt=%d: %llu px, dec %llu px\n", R, W, rows, cols, nt, bad, bad_dec); ++fails; }
+    // u8 source upsampled on the fly (rows, cols must be even here)
+    if (!(rows & 1) && !(cols & 1)) {
+        const int ur = rows / 2, uc = cols / 2;
+        hipLaunchKernelGGL(fill_u8, dim3((unsigned)(((size_t)ur * uc + 255) / 256)), dim3(256), 0, 0, u8, (size_t)ur * uc, 5u + R);
+        hipLaunchKernelGGL(ref_up, grid, dim3(256), 0, 0, (const uint8_t*)u8, ur, uc, src);
+        hipLaunchKernelGGL(ref_rows, grid, dim3(256), 0, 0, (const float*)src, tmp, rows, cols, g);
+        hipLaunchKernelGGL(ref_cols, grid, dim3(256), 0, 0, (const float*)tmp, ref, rows, cols, g);
+        CK(hipMemset(dst, 0xff, n * 4));
+        blur_march_launch<R, W, true>(0, u8, dst, nullptr, rows, cols, uc, k, 1, 0, 0, nt);
+        CK(hipDeviceSynchronize());
+        bad = count_bad(ref, dst, n);
+        if (bad) { printf("  MISMATCH u8-up R=%d W=%d %dx%d nt=%d: %llu px\n", R, W, rows, cols, nt, bad); ++fails; }
+    }
+    return fails;
 }
+
+template <int R, int W, bool UP>
+static float timeit(int rows, int cols, int batch, int nt, const void* src, float* dst, float* dec, size_t src_zs, size_t zs) {
+    float k[2 * R + 1];
+    gauss(R, k);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    blur_march_launch<R, W, UP>(0, src, dst, dec, rows, cols, cols / 2, k, batch, src_zs, zs, nt);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 3; ++i) blur_march_launch<R, W, UP>(0, src, dst, dec, rows, cols, cols / 2, k, batch, src_zs, zs, nt);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / 3;
+}
+
+template <int R>
+static int run_radius(float* src, float* tmp, float* ref, float* dst, float* dec, uint8_t* u8) {
+    int fails = 0;
+    const int shapes[][2] = {{123, 157}, {240, 320}, {66, 64}, {960, 1280}, {1000, 1004}, {34, 36}, {2048, 4096}};
+    for (auto& s : shapes) {
+        if (s[0] <= R || s[1] <= R) continue;
+        fails += check<R, 64>(s[0], s[1], 1, src, tmp, ref, dst, dec, u8);
+        fails += check<R, 64>(s[0], s[1], 3, src, tmp, ref, dst, dec, u8);
+        fails += check<R, 128>(s[0], s[1], 2, src, tmp, ref, dst, dec, u8);
+    }
+    printf("R=%d exactness: %s\n", R, fails ? "FAILED" : "ok");
+    const int n = 16384;
+    const double gb = (double)n * n * 8 / 1e9;
+    for (int nt : {4, 8, 16, 32}) {
+        const float a = timeit<R, 64, false>(n, n, 1, nt, src, dst, nullptr, 0, 0);
+        const float b = timeit<R, 128, false>(n, n, 1, nt, src, dst, nullptr, 0, 0);
+        printf("R=%2d 16384^2 nt=%2d  W64 %.3f ms (%.2f TB/s of 8 B/px)  W128 %.3f ms (%.2f TB/s)\n", R, nt, a, gb / a, b, gb / b);
+    }
+    {
+        const float a = timeit<R, 64, false>(n, n, 1, 8, src, dst, dec, 0, 0);
+        printf("R=%2d 16384^2 nt= 8  W64 + decimated output %.3f ms\n", R, a);
+        const float u = timeit<R, 64, true>(n, n, 1, 8, u8, dst, nullptr, 0, 0);
+        const float u2 = timeit<R, 128, true>(n, n, 1, 8, u8, dst, nullptr, 0, 0);
+        printf("R=%2d 16384^2 nt= 8  u8-upsampled source W64 %.3f ms  W128 %.3f ms\n", R, u, u2);
+    }
+    const size_t zs = (size_t)960 * 1280 * 4;
+    for (int nt : {1, 2, 4}) {
+        const float a = timeit<R, 64, false>(960, 1280, 32, nt, src, dst, nullptr, zs, zs);
+        const float b = timeit<R, 64, false>(960, 1280, 1, nt, src, dst, nullptr, zs, zs);
+        printf("R=%2d 960x1280 nt=%d  x32 %.4f ms   x1 %.4f ms\n", R, nt, a, b);
+    }
+    return fails;
+}
+
 int main() {
-    const int n = 16384; const size_t px = (size_t)n * n;
-    float *s, *d, *g; hipMalloc(&s, px * 4); hipMalloc(&d, px * 4); hipMalloc(&g, px * 4);
-    hipMemset(s, 0x3c, px * 4);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(copy_kernel, dim3(px / 4 / 256), dim3(256), 0, 0, (const float4*)s, (float4*)d, (float4*)g, px / 4);
-    hipEventRecord(e0);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(copy_kernel, dim3(px / 4 / 256), dim3(256), 0, 0, (const float4*)s, (float4*)d, (float4*)g, px / 4);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("copy 1r+2w: %.3f ms  %.2f TB/s\n", ms / 3, px * 12.0 / (ms / 3 * 1e-3) / 1e12);
-    printf("R=13 full %.3f | load-only %.3f | load+row %.3f | compute-only %.3f ms\n", run<13, 0>(s, d, g, n), run<13, 1>(s, d, g, n), run<13, 2>(s, d, g, n), run<13, 3>(s, d, g, n));
-    printf("R=5  full %.3f | load-only %.3f | load+row %.3f | compute-only %.3f ms\n", run<5, 0>(s, d, g, n), run<5, 1>(s, d, g, n), run<5, 2>(s, d, g, n), run<5, 3>(s, d, g, n));
-    printf("R=8  full %.3f | load-only %.3f | load+row %.3f | compute-only %.3f ms\n", run<8, 0>(s, d, g, n), run<8, 1>(s, d, g, n), run<8, 2>(s, d, g, n), run<8, 3>(s, d, g, n));
-    return 0;
+    const int n = 16384;
+    const size_t px = (size_t)n * n;
+    float *src, *tmp, *ref, *dst, *dec;
+    uint8_t* u8;
+    CK(hipMalloc(&src, px * 4)); CK(hipMalloc(&tmp, px * 4)); CK(hipMalloc(&ref, px * 4)); CK(hipMalloc(&dst, px * 4));
+    CK(hipMalloc(&dec, px)); CK(hipMalloc(&u8, px / 4)); CK(hipMalloc(&d_bad, 8));
+    int fails = 0;
+    fails += run_radius<5>(src, tmp, ref, dst, dec, u8);
+    fails += run_radius<6>(src, tmp, ref, dst, dec, u8);
+    fails += run_radius<8>(src, tmp, ref, dst, dec, u8);
+    fails += run_radius<10>(src, tmp, ref, dst, dec, u8);
+    fails += run_radius<13>(src, tmp, ref, dst, dec, u8);
+    fails += check<13, 64>(n, n, 16, src, tmp, ref, dst, dec, u8);
+    fails += check<5, 64>(n, n, 16, src, tmp, ref, dst, dec, u8);
+    printf("16384^2 exactness (R=13, R=5): %s\n", fails ? "FAILED" : "ok");
+    return fails ? 1 : 0;
 }
