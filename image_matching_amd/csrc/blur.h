@@ -28,6 +28,7 @@ template <int R>
 struct GK { float k[2 * R + 1]; };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (p < 0) p = -p;                       // one fold each way covers every halo narrower than the image
@@ -54,9 +55,20 @@ __device__ __forceinline__ float upsample2_value(const uint8_t* __restrict__ s, 
 }
 
 #define BM_CH 32  // rows per chunk
+// Workgroups per CU the kernel is compiled for. R = 13 at 4 (128 VGPRs) spills its row-pass window and runs
+// 0.75 ms per 16384^2 layer against 0.61 ms at 3; R = 10 is the other way round (0.50 vs 0.56 ms).
+#ifndef BM_MINB_BIG
+#define BM_MINB_BIG 3
+#endif
+// Output rows are not read again by this launch: nontemporal stores keep them from displacing the halo
+// columns neighbouring strips share through L2 (about 3 % per layer).
+#ifndef BM_NT_STORE
+#define BM_NT_STORE 1
+#endif
 
-template <int R, int W, bool UP>
-__global__ void __launch_bounds__(256, (W == 64 ? 4 : 2))
+// ABL (tools/blur_bench.hip only): 1 = row pass reduced to its centre tap, 2 = column pass likewise.
+template <int R, int W, bool UP, int ABL = 0>
+__global__ void __launch_bounds__(256, (W == 64 ? (R >= 12 ? BM_MINB_BIG : 4) : 2))
 blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float* __restrict__ dec, int rows, int cols,
                   int ustride, GK<R> gk, int nt, int nstrip, int nseg, size_t src_zs, size_t zs) {
     static_assert(R >= 1 && R <= 16, "the 64-row ring holds 32 + 2R rows");
@@ -64,8 +76,15 @@ blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float*
     constexpr int N = 2 * R + 1, CH = BM_CH, NP = CH / 2;
     constexpr int XO = (R + 3) & ~3, P = W + 2 * XO, NX4 = P / 4;
     constexpr int NITEM = NP * NX4, NIT = (NITEM + 255) / 256;
-    __shared__ float in[NP * P * 2];
+    // `in` holds row pairs interleaved: element (row 2*yp + par, col) is float ((yp * PL + col) * 2 + par), so one
+    // 16-byte read yields (y,x) (y+1,x) (y,x+1) (y+1,x+1). The pair pitch 2*PL is 4 mod 8 dwords: the 16-lane
+    // groups of a ds_read_b128 then take their two row pairs from complementary 16-byte slots (conflict-free;
+    // a pitch of 0 mod 8 is 2-way). The array is float4-typed so the reads are provably aligned (ds_read_b128,
+    // not ds_read2_b64, which runs at half the rate and banks mod 32).
+    constexpr int PL = P + 2;
+    __shared__ float4 in4[NP * PL / 2];
     __shared__ float ring[64 * W];
+    float* const in = (float*)in4;
 
     const int tid = threadIdx.x;
     int strip, seg;
@@ -119,7 +138,7 @@ blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float*
             }
         }
     };
-    // ... -> LDS, element (row 2*yp + par, col) at ((yp * P + col) * 2 + par)
+    // ... -> LDS
     auto land = [&](int np) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -151,7 +170,7 @@ blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float*
             const int item = tid + it * 256;
             if (item < np * NX4) {
                 const int yp = item / NX4, x4 = item - yp * NX4;
-                float4* l = (float4*)&in[(yp * P + 4 * x4) * 2];
+                float4* l = &in4[yp * (PL / 2) + 2 * x4];
                 l[0] = make_float4(pa[it].x, pb[it].x, pa[it].y, pb[it].y);
                 l[1] = make_float4(pa[it].z, pb[it].z, pa[it].w, pb[it].w);
             }
@@ -172,7 +191,10 @@ blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float*
 #pragma unroll
         for (int it = 0; it < NE; ++it) {
             const int f = tid + it * 256;
-            if (f < ne) in[f] = e[it];
+            if (f < ne) {
+                const int yp = f / (2 * P), rem = f - yp * (2 * P);
+                in[yp * (2 * PL) + rem] = e[it];
+            }
         }
     };
     auto chunk_fast = [&](int yin, int np) { return colfast && yin >= 0 && yin + 2 * np <= rows; };
@@ -185,14 +207,17 @@ blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float*
             f2 v[E1 - E0];
 #pragma unroll
             for (int i = 0; i < (E1 - E0) / 2; ++i) {
-                const float4 q = *(const float4*)&in[(yp * P + xq + E0 + 2 * i) * 2];
+                // the empty asm keeps the 16-byte read whole: when the first tap sits in the upper half (odd
+                // XO - R) the compiler otherwise re-slices the window into misaligned ds_read2_b64 pairs
+                f4 q = *(const f4*)&in4[yp * (PL / 2) + (xq + E0) / 2 + i];
+                asm("" : "+v"(q));
                 v[2 * i] = f2{q.x, q.y};
                 v[2 * i + 1] = f2{q.z, q.w};
             }
             f2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
 #pragma unroll
-            for (int t = 0; t < N; ++t) {
-                const f2 k = {gk.k[t], gk.k[t]};
+            for (int t = (ABL & 1) ? R : 0; t < ((ABL & 1) ? R + 1 : N); ++t) {
+                const f2 k = {gk.k[t <= R ? t : 2 * R - t], gk.k[t <= R ? t : 2 * R - t]};   // symmetric: R + 1 distinct taps to hold
                 a0 = __builtin_elementwise_fma(k, v[OFF + t], a0);
                 a1 = __builtin_elementwise_fma(k, v[OFF + t + 1], a1);
                 a2 = __builtin_elementwise_fma(k, v[OFF + t + 2], a2);
@@ -238,8 +263,8 @@ blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float*
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = f2{0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < N; ++t) {
-                const f2 k = {gk.k[t], gk.k[t]};
+            for (int t = (ABL & 2) ? R : 0; t < ((ABL & 2) ? R + 1 : N); ++t) {
+                const f2 k = {gk.k[t <= R ? t : 2 * R - t], gk.k[t <= R ? t : 2 * R - t]};   // symmetric: R + 1 distinct taps to hold
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = __builtin_elementwise_fma(k, v[t + j], acc[j]);
             }
@@ -251,7 +276,8 @@ blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float*
                 if (gy >= y_end || gx >= cols) continue;
                 const size_t o = (size_t)gy * cols + gx;
                 if (pair_ok) {
-                    *(f2*)&dst[o] = acc[j];
+                    if (BM_NT_STORE) __builtin_nontemporal_store(acc[j], (f2*)&dst[o]);
+                    else *(f2*)&dst[o] = acc[j];
                 } else {
                     dst[o] = acc[j].x;
                     if (gx + 1 < cols) dst[o + 1] = acc[j].y;
@@ -265,18 +291,19 @@ blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float*
 
 // Host launcher. nt = chunks of 32 rows a workgroup marches through (0: chosen here so that the launch
 // still has several workgroups per CU slot).
-template <int R, int W, bool UP>
+template <int R, int W, bool UP, int ABL = 0>
 static inline void blur_march_launch(hipStream_t st, const void* src, float* dst, float* dec, int rows, int cols, int ustride,
                                      const float* k, int batch, size_t src_zs, size_t zs, int nt = 0) {
     GK<R> gk;
     for (int i = 0; i < 2 * R + 1; ++i) gk.k[i] = k[i];
     const int nstrip = (cols + W - 1) / W, nchunk = (rows + BM_CH - 1) / BM_CH;
     if (nt <= 0) {
-        // at least ~8 workgroups per CU (256 CUs) before the march gets longer; at most 16 chunks
+        // at least 16 workgroups per CU (256 CUs, 4 resident each) before the march gets longer; at most 16 chunks
+        // (tools/blur_bench.hip: 8192^2 is 8 % faster at nt = 8 than at 16, 16384^2 the other way round)
         nt = 16;
-        while (nt > 1 && (long long)nstrip * ((nchunk + nt - 1) / nt) * batch < 2048) nt >>= 1;
+        while (nt > 1 && (long long)nstrip * ((nchunk + nt - 1) / nt) * batch < 4096) nt >>= 1;
     }
     const int nseg = (nchunk + nt - 1) / nt, total = nstrip * nseg;
-    hipLaunchKernelGGL((blur_march_kernel<R, W, UP>), dim3((unsigned)((total + 7) & ~7), 1, (unsigned)batch), dim3(256), 0, st,
+    hipLaunchKernelGGL((blur_march_kernel<R, W, UP, ABL>), dim3((unsigned)((total + 7) & ~7), 1, (unsigned)batch), dim3(256), 0, st,
                        src, dst, dec, rows, cols, ustride, gk, nt, nstrip, nseg, src_zs, zs);
 }

@@ -65,10 +65,12 @@ struct imatch_sift_state {
     PyrTable T;
     int h, w;
     int ref_hint, kp_hint;  // list lengths of the previous extraction: launch-grid and download-size guesses
-    // Layers nl+1, nl+2 and the extremum scan of an octave are not needed by the next octave: they run
-    // on this second stream, forked after layer nl and joined before the refinement.
+    // Octave 1 needs only layer nl of octave 0, and an octave's six kernels depend on one another in a
+    // chain: on large images octave 0's layers nl+1, nl+2 and scan (main stream) run beside ALL later octaves
+    // (this second stream, forked after octave 0's layer nl, joined before the refinement). The later
+    // octaves are a quarter of the bytes but mostly launch latency, which the overlap hides.
     hipStream_t side;
-    hipEvent_t ev_fork[MAX_OCT], ev_join;
+    hipEvent_t ev_fork, ev_join;
 };
 
 void imatch_sift_state_free(imatch_ctx* ctx) {
@@ -76,7 +78,7 @@ void imatch_sift_state_free(imatch_ctx* ctx) {
     if (ctx->sift->arena) (void)hipFree(ctx->sift->arena);
     if (ctx->sift->side) {
         (void)hipStreamSynchronize(ctx->sift->side);
-        for (int i = 0; i < MAX_OCT; ++i) (void)hipEventDestroy(ctx->sift->ev_fork[i]);
+        (void)hipEventDestroy(ctx->sift->ev_fork);
         (void)hipEventDestroy(ctx->sift->ev_join);
         (void)hipStreamDestroy(ctx->sift->side);
     }
@@ -313,6 +315,8 @@ detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ 
     for (int l = 0; l < 6; ++l) p[l] = TG(o, l) + xc;
     const bool col_ok = lane >= 1 && lane <= DS_COLS && x < cols - SIFT_IMG_BORDER;
     float hm[5][3], hn[5][3], cv[3][3];
+    // (Requesting row r + 2 before reducing row r + 1 was tried: 1.43 -> 1.58 ms on the 16384^2 octave; the walk
+    // is not latency-bound at 8 waves per SIMD.)
     auto load_row = [&](int row, int slot) {
         const size_t off = (size_t)min(row, rows - 1) * cols;
         float g[6];
@@ -1152,7 +1156,11 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         T.cols[o] = o == 0 ? bcols : T.cols[o - 1] / 2;
         if (T.rows[o] < 1 || T.cols[o] < 1) { n_oct = o; break; }
         const size_t px = (size_t)T.rows[o] * T.cols[o] * 4;
-        for (int i = 0; i < nl + 3; ++i) o_g[o][i] = take(px);
+        // Large layers are staggered: a 16384^2 layer is exactly 2^30 bytes, and with the layers back to back a
+        // kernel's read and write streams (row y of layer i, row y of layer i+1; the scan's six layers) sit on the
+        // same HBM channels at every instant (tools/blur_bench.hip `pipe`: R = 13 0.83 ms -> 0.68 ms with the gap).
+        const size_t stagger = px >= ((size_t)16 << 20) ? (size_t)1057024 : 0;
+        for (int i = 0; i < nl + 3; ++i) { o_g[o][i] = take(px); (void)take(stagger); }
     }
     T.n_oct = n_oct;
     int cap = (int)std::min<size_t>((size_t)brows * bcols / 8 + 16384, (size_t)1 << 28);
@@ -1228,39 +1236,41 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // octaves from o_tail on go to the single-workgroup kernel
         int o_tail = n_oct;
         for (int o = n_oct - 1; o >= 1 && (size_t)T.rows[o] * T.cols[o] <= TAIL_MAXPX; --o) o_tail = o;
-        // fork/join (see imatch_sift_state); the runtime-radius blur shares d_tmp, so it stays on one stream
-        // An event record + cross-stream wait costs ~20 us per octave (tools/launch_bench.hip), more than a
-        // camera frame's octave gains; on a map the overlap fills the tails of the big launches.
-        bool use_side = all_templated && (size_t)brows * bcols * batch >= ((size_t)1 << 22);
+        // fork/join (see imatch_sift_state); the runtime-radius blur shares d_tmp, so it stays on one stream.
+        // An event record + cross-stream wait costs ~20 us (tools/launch_bench.hip), so small work stays serial.
+        bool use_side = all_templated && n_oct > 1 && (size_t)brows * bcols * batch >= ((size_t)1 << 22);
+        if (const char* e = getenv("IMATCH_SIFT_SIDE")) use_side = use_side && atoi(e) != 0;   // experiments
         if (use_side && !S->side) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&S->side, hipStreamNonBlocking));
-            for (int i = 0; i < MAX_OCT; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_fork[i], hipEventDisableTiming));
+            // highest priority: the later octaves' small launches must get CU slots while octave 0's big kernels
+            // are resident, or they queue behind them and the overlap is lost
+            int prio_least = 0, prio_greatest = 0;
+            HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            HIP_TRY(ctx, hipStreamCreateWithPriority(&S->side, hipStreamNonBlocking, prio_greatest));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming));
         }
         hipStream_t st2 = use_side ? S->side : ctx->stream;
         bool have_l0 = true;   // layer 0 of octave o was written by the previous octave's layer-nl blur
         for (int o = 0; o < o_tail; ++o) {
             const int rows = T.rows[o], cols = T.cols[o];
+            hipStream_t st = o == 0 ? ctx->stream : st2;
             if (o > 0 && !have_l0)
-                hipLaunchKernelGGL(decimate_kernel, dim3((cols + 63) / 64, (rows + 3) / 4, batch), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(decimate_kernel, dim3((cols + 63) / 64, (rows + 3) / 4, batch), dim3(256), 0, st,
                                    (const float*)T.gauss[o - 1][nl], T.cols[o - 1], T.gauss[o][0], rows, cols, zs);
-            for (int i = 1; i <= nl; ++i) {
+            for (int i = 1; i < nl + 3; ++i) {
                 // the tail kernel decimates for itself, so only octaves that stay on this path get the fused output
                 float* dec = (i == nl && o + 1 < o_tail) ? T.gauss[o + 1][0] : nullptr;
                 bool fz = true;
-                rc = gaussian_blur(ctx, ctx->stream, T.gauss[o][i - 1], nullptr, 0, 0, T.gauss[o][i], dec, d_tmp, rows, cols, sig[i],
-                                   batch, zs, &fz);
+                rc = gaussian_blur(ctx, st, T.gauss[o][i - 1], nullptr, 0, 0, T.gauss[o][i], dec, d_tmp, rows, cols, sig[i], batch, zs,
+                                   &fz);
                 if (rc) return rc;
-                if (i == nl) have_l0 = dec != nullptr && fz;
-            }
-            if (use_side) {
-                HIP_TRY(ctx, hipEventRecord(S->ev_fork[o], ctx->stream));
-                HIP_TRY(ctx, hipStreamWaitEvent(st2, S->ev_fork[o], 0));
-            }
-            for (int i = nl + 1; i < nl + 3; ++i) {
-                rc = gaussian_blur(ctx, st2, T.gauss[o][i - 1], nullptr, 0, 0, T.gauss[o][i], nullptr, d_tmp, rows, cols, sig[i], batch,
-                                   zs, nullptr);
-                if (rc) return rc;
+                if (i == nl) {
+                    have_l0 = dec != nullptr && fz;
+                    if (o == 0 && use_side) {   // the later octaves need nothing else of octave 0
+                        HIP_TRY(ctx, hipEventRecord(S->ev_fork, ctx->stream));
+                        HIP_TRY(ctx, hipStreamWaitEvent(st2, S->ev_fork, 0));
+                    }
+                }
             }
             if (rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER) {
                 const int iw = cols - 2 * SIFT_IMG_BORDER, ih = rows - 2 * SIFT_IMG_BORDER;
@@ -1268,14 +1278,15 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                     const size_t px = (size_t)iw * ih * batch;
                     const int rpw = px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
                     hipLaunchKernelGGL(detect_stream_kernel,
-                                       dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * rpw - 1) / (4 * rpw), batch), dim3(256), 0, st2,
+                                       dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * rpw - 1) / (4 * rpw), batch), dim3(256), 0, st,
                                        T, o, rpw, thr, d_cand, cap, d_cnt, zs);
                 } else {
                     hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H, batch),
-                                       dim3(256), 0, st2, T, o, thr, d_cand, cap, d_cnt, zs);
+                                       dim3(256), 0, st, T, o, thr, d_cand, cap, d_cnt, zs);
                 }
             }
         }
+        hipStream_t st_tail = st2;   // o_tail >= 1: the tail needs layer nl of octave o_tail - 1, which precedes it on st2 (or the fork)
         bool tail_fast = o_tail < n_oct && nl == 3 &&
                          (size_t)tf_ext_rows(T.rows[o_tail]) * tf_pitch(T.cols[o_tail]) <= TF_EXT;
         TailFK tfk;
@@ -1295,7 +1306,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                 attr_set[ctx->device & 63] = true;
             }
             hipLaunchKernelGGL((pyramid_tail_fast_kernel<5, 6, 8, 10, 13>), dim3(1, 1, batch), dim3(1024), TF_LDS_BYTES,
-                               ctx->stream, T, o_tail, tfk, thr, d_cand, cap, d_cnt, zs);
+                               st_tail, T, o_tail, tfk, thr, d_cand, cap, d_cnt, zs);
         } else if (o_tail < n_oct) {
             TailK tk;
             memset(&tk, 0, sizeof(tk));
@@ -1310,7 +1321,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                                                  TAIL_LDS_BYTES));
                 attr_set[ctx->device & 63] = true;
             }
-            hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1, 1, batch), dim3(1024), TAIL_LDS_BYTES, ctx->stream, T, o_tail, tk,
+            hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1, 1, batch), dim3(1024), TAIL_LDS_BYTES, st_tail, T, o_tail, tk,
                                thr, d_cand, cap, d_cnt, zs);
         }
         HIP_TRY(ctx, hipGetLastError());

@@ -122,15 +122,15 @@ static int check(int rows, int cols, int nt, float* src, float* tmp, float* ref,
     return fails;
 }
 
-template <int R, int W, bool UP>
+template <int R, int W, bool UP, int ABL = 0>
 static float timeit(int rows, int cols, int batch, int nt, const void* src, float* dst, float* dec, size_t src_zs, size_t zs) {
     float k[2 * R + 1];
     gauss(R, k);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    blur_march_launch<R, W, UP>(0, src, dst, dec, rows, cols, cols / 2, k, batch, src_zs, zs, nt);
+    blur_march_launch<R, W, UP, ABL>(0, src, dst, dec, rows, cols, cols / 2, k, batch, src_zs, zs, nt);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < 3; ++i) blur_march_launch<R, W, UP>(0, src, dst, dec, rows, cols, cols / 2, k, batch, src_zs, zs, nt);
+    for (int i = 0; i < 3; ++i) blur_march_launch<R, W, UP, ABL>(0, src, dst, dec, rows, cols, cols / 2, k, batch, src_zs, zs, nt);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -157,11 +157,22 @@ static int run_radius(float* src, float* tmp, float* ref, float* dst, float* dec
         printf("R=%2d 16384^2 nt=%2d  W64 %.3f ms (%.2f TB/s of 8 B/px)  W128 %.3f ms (%.2f TB/s)\n", R, nt, a, gb / a, b, gb / b);
     }
     {
+        const float a1 = timeit<R, 64, false, 1>(n, n, 1, 16, src, dst, nullptr, 0, 0);
+        const float a2 = timeit<R, 64, false, 2>(n, n, 1, 16, src, dst, nullptr, 0, 0);
+        const float a3 = timeit<R, 64, false, 3>(n, n, 1, 16, src, dst, nullptr, 0, 0);
+        printf("R=%2d 16384^2 nt=16  W64 ablation: centre-tap row pass %.3f | centre-tap column pass %.3f | both %.3f ms\n", R, a1, a2, a3);
+    }
+    {
         const float a = timeit<R, 64, false>(n, n, 1, 8, src, dst, dec, 0, 0);
         printf("R=%2d 16384^2 nt= 8  W64 + decimated output %.3f ms\n", R, a);
         const float u = timeit<R, 64, true>(n, n, 1, 8, u8, dst, nullptr, 0, 0);
         const float u2 = timeit<R, 128, true>(n, n, 1, 8, u8, dst, nullptr, 0, 0);
         printf("R=%2d 16384^2 nt= 8  u8-upsampled source W64 %.3f ms  W128 %.3f ms\n", R, u, u2);
+    }
+    for (int m : {8192, 4096, 2048}) {
+        printf("R=%2d %5d^2 W64:", R, m);
+        for (int nt : {1, 2, 4, 8, 16}) printf("  nt=%d %.4f", nt, timeit<R, 64, false>(m, m, 1, nt, src, dst, nullptr, 0, 0));
+        printf(" ms\n");
     }
     const size_t zs = (size_t)960 * 1280 * 4;
     for (int nt : {1, 2, 4}) {
@@ -172,7 +183,48 @@ static int run_radius(float* src, float* tmp, float* ref, float* dst, float* dec
     return fails;
 }
 
-int main() {
+// the five blurs of an octave back to back, layers `gap` bytes apart in one allocation (the product's arena layout)
+template <int R>
+static void one(const float* a, float* b, int n) {
+    float k[2 * R + 1];
+    gauss(R, k);
+    blur_march_launch<R, 64, false>(0, a, b, nullptr, n, n, 0, k, 1, 0, 0, 0);
+}
+static void pipeline(size_t gap_extra, bool sync_between) {
+    const int n = 16384;
+    const size_t px = (size_t)n * n, gap = px * 4 + gap_extra;
+    char* arena;
+    CK(hipMalloc(&arena, gap * 6));
+    hipLaunchKernelGGL(fill_f32, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, 0, (float*)arena, px, 3u);
+    hipEvent_t e[6];
+    for (auto& x : e) CK(hipEventCreate(&x));
+    auto L = [&](int i) { return (float*)(arena + gap * i); };
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e[0]));
+        one<5>(L(0), L(1), n); CK(hipEventRecord(e[1])); if (sync_between) CK(hipDeviceSynchronize());
+        one<6>(L(1), L(2), n); CK(hipEventRecord(e[2])); if (sync_between) CK(hipDeviceSynchronize());
+        one<8>(L(2), L(3), n); CK(hipEventRecord(e[3])); if (sync_between) CK(hipDeviceSynchronize());
+        one<10>(L(3), L(4), n); CK(hipEventRecord(e[4])); if (sync_between) CK(hipDeviceSynchronize());
+        one<13>(L(4), L(5), n); CK(hipEventRecord(e[5]));
+        CK(hipDeviceSynchronize());
+        float t[5];
+        for (int i = 0; i < 5; ++i) CK(hipEventElapsedTime(&t[i], e[i], e[i + 1]));
+        printf("pipeline gap 2^30+%zu %s: R5 %.3f  R6 %.3f  R8 %.3f  R10 %.3f  R13 %.3f ms\n", gap_extra,
+               sync_between ? "host sync between" : "queued back to back", t[0], t[1], t[2], t[3], t[4]);
+    }
+    CK(hipFree(arena));
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) {
+        CK(hipMalloc(&d_bad, 8));
+        pipeline(0, true);
+        pipeline(0, false);
+        pipeline((1 << 20) + 8192 + 256, true);
+        pipeline((1 << 20) + 8192 + 256, false);
+        return 0;
+    }
     const int n = 16384;
     const size_t px = (size_t)n * n;
     float *src, *tmp, *ref, *dst, *dec;
