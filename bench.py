@@ -6,7 +6,7 @@ Metric (BASELINE.json): frames/sec of the full chain CLAHE -> SIFT -> kNN(k=2)+r
 reference's map.png is not in its tree, so the "full map" is the seeded synthetic 8192x8192 orthomap of
 SURVEY.md 8d). Gdist/s of the kNN stage is reported beside it.
 
-A step = every rank takes ONE BATCH of --batch frames (default 32, already in HBM as one [B,480,640] tensor)
+A step = every rank takes ONE BATCH of --batch frames (default 64, already in HBM as one [B,480,640] tensor)
 through the batched entry points: extract (every kernel launched once for the batch) -> one kNN launch
 over all the batch's keypoints against the whole map -> ratio -> homography per frame (iff > 10 good
 matches, position_finder.py:316). Per frame the results are identical to the single-frame entry points
@@ -72,9 +72,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--map-side", type=int, default=8192)
-    ap.add_argument("--frames", type=int, default=64, help="distinct synthetic frames per rank, cycled")
+    ap.add_argument("--frames", type=int, default=128, help="distinct synthetic frames per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=32,
+    ap.add_argument("--batch", type=int, default=64,
                     help="frames per step and GPU, taken through the batched entry points (one launch per stage for "
                          "the whole batch, one kNN launch over all frames' keypoints); 1 = the single-frame calls")
     ap.add_argument("--streams", type=int, default=1,
@@ -313,7 +313,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r1_pmc_knn.json")) as fh:
                 pmc = json.load(fh)
-            if world == 1 and B == 32 and abs(pmc.get("n_queries", q_mean) - q_mean) < 0.05 * q_mean:
+            if world == 1 and B == pmc.get("batch", 32) and abs(pmc.get("n_queries", q_mean) - q_mean) < 0.05 * q_mean:
                 out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_note"] = "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE, " + pmc["source"]
         except (OSError, ValueError, KeyError):

@@ -16,6 +16,9 @@ struct imatch_ctx {
     // pinned host staging
     void* hs;
     size_t hs_bytes;
+    // pinned staging of host images on their way to / from the device (see imatch_stage_upload)
+    void* is;
+    size_t is_bytes;
     // optional event bracket around the dominant kernel (imatch_set_profiling)
     int prof;
     hipEvent_t ev0, ev1;   // kNN MFMA kernel
@@ -69,6 +72,14 @@ void* imatch_pool_alloc(imatch_ctx* ctx, size_t bytes);
 void imatch_pool_free(imatch_ctx* ctx, void* p);
 void imatch_pool_destroy(imatch_ctx* ctx);
 int imatch_hs_reserve(imatch_ctx* ctx, size_t bytes);
+// Host images are pageable numpy memory: an asynchronous 2-D copy from it degenerates into one small
+// transfer per row (6 ms for a 1280x720 frame). The rows are packed into a pinned block first and go up
+// in one transfer; a download lands in the block's second part and is copied out after the caller's
+// synchronisation. Every user synchronises ctx->stream before it returns, so the block is free again by
+// the next call.
+int imatch_stage_upload(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, uint8_t* dev);
+int imatch_stage_download_begin(imatch_ctx* ctx, const uint8_t* dev, size_t bytes);   // queued on ctx->stream
+void imatch_stage_download_end(imatch_ctx* ctx, uint8_t* out, size_t bytes);          // after the synchronisation
 
 #define HIP_TRY(ctx, call)                                                              \
     do {                                                                                \

@@ -27,6 +27,48 @@ int imatch_ws_reserve(imatch_ctx* ctx, size_t bytes) {
     return IMATCH_OK;
 }
 
+static int is_reserve(imatch_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->is_bytes) return IMATCH_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->is) HIP_TRY(ctx, hipHostFree(ctx->is));
+    ctx->is = nullptr;
+    ctx->is_bytes = 0;
+    if (hipHostMalloc(&ctx->is, bytes, hipHostMallocDefault) != hipSuccess)
+        return imatch_set_err(ctx, IMATCH_ENOMEM, "pinned image staging of %zu bytes", bytes);
+    ctx->is_bytes = bytes;
+    return IMATCH_OK;
+}
+
+// the block is split in halves: [0, half) uploads, [half, 2*half) downloads
+static size_t is_half(const imatch_ctx* ctx) { return ctx->is_bytes / 2; }
+
+int imatch_stage_upload(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, uint8_t* dev) {
+    const size_t bytes = (size_t)h * w;
+    if (bytes > is_half(ctx)) {
+        int rc = is_reserve(ctx, 2 * (bytes + bytes / 4 + 4096));
+        if (rc) return rc;
+    }
+    uint8_t* st = (uint8_t*)ctx->is;
+    if (stride == w) memcpy(st, img, bytes);
+    else
+        for (int y = 0; y < h; ++y) memcpy(st + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
+    HIP_TRY(ctx, hipMemcpyAsync(dev, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return IMATCH_OK;
+}
+
+int imatch_stage_download_begin(imatch_ctx* ctx, const uint8_t* dev, size_t bytes) {
+    if (bytes > is_half(ctx)) {
+        int rc = is_reserve(ctx, 2 * (bytes + bytes / 4 + 4096));   // synchronises: nothing of this call is lost, the
+        if (rc) return rc;                                          // upload half has been consumed by then
+    }
+    HIP_TRY(ctx, hipMemcpyAsync((uint8_t*)ctx->is + is_half(ctx), dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return IMATCH_OK;
+}
+
+void imatch_stage_download_end(imatch_ctx* ctx, uint8_t* out, size_t bytes) {
+    memcpy(out, (const uint8_t*)ctx->is + is_half(ctx), bytes);
+}
+
 int imatch_hs_reserve(imatch_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->hs_bytes) return IMATCH_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -143,6 +185,7 @@ void imatch_destroy(imatch_ctx* ctx) {
     imatch_pool_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->hs) (void)hipHostFree(ctx->hs);
+    if (ctx->is) (void)hipHostFree(ctx->is);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);

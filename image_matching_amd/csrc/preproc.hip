@@ -220,12 +220,6 @@ int imatch_resize_area_dev(imatch_ctx* ctx, const uint8_t* src_dev, int h, int w
 }
 
 // ---- host-pointer entry points ---------------------------------------------------------------
-static int upload_image(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, uint8_t* dev) {
-    HIP_TRY(ctx, hipMemcpy2DAsync(dev, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice,
-                                  ctx->stream));
-    return IMATCH_OK;
-}
-
 extern "C" {
 
 int imatch_clahe(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, double clip_limit, int tiles_x,
@@ -239,12 +233,14 @@ int imatch_clahe(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, 
     if (rc) return rc;
     uint8_t* src = (uint8_t*)ctx->ws;
     uint8_t* dst = src + px;
-    rc = upload_image(ctx, img, h, w, stride, src);
+    rc = imatch_stage_upload(ctx, img, h, w, stride, src);
     if (rc) return rc;
     rc = imatch_clahe_dev(ctx, src, h, w, w, clip_limit, tiles_x, tiles_y, dst, dst + px);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out, dst, (size_t)h * w, hipMemcpyDeviceToHost, ctx->stream));
+    rc = imatch_stage_download_begin(ctx, dst, (size_t)h * w);
+    if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    imatch_stage_download_end(ctx, out, (size_t)h * w);
     return IMATCH_OK;
 }
 
@@ -259,12 +255,14 @@ int imatch_resize_area(imatch_ctx* ctx, const uint8_t* img, int h, int w, int st
     if (rc) return rc;
     uint8_t* src = (uint8_t*)ctx->ws;
     uint8_t* dst = src + px;
-    rc = upload_image(ctx, img, h, w, stride, src);
+    rc = imatch_stage_upload(ctx, img, h, w, stride, src);
     if (rc) return rc;
     rc = imatch_resize_area_dev(ctx, src, h, w, w, dst, dh, dw);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out, dst, (size_t)dh * dw, hipMemcpyDeviceToHost, ctx->stream));
+    rc = imatch_stage_download_begin(ctx, dst, (size_t)dh * dw);
+    if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    imatch_stage_download_end(ctx, out, (size_t)dh * dw);
     return IMATCH_OK;
 }
 

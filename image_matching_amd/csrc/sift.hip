@@ -1158,7 +1158,8 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         const size_t px = (size_t)T.rows[o] * T.cols[o] * 4;
         // Large layers are staggered: a 16384^2 layer is exactly 2^30 bytes, and with the layers back to back a
         // kernel's read and write streams (row y of layer i, row y of layer i+1; the scan's six layers) sit on the
-        // same HBM channels at every instant (tools/blur_bench.hip `pipe`: R = 13 0.83 ms -> 0.68 ms with the gap).
+        // same HBM channels at every instant (tools/blur_bench.hip `pipe`: R = 13 0.83 ms -> 0.68 ms with the gap;
+        // inside the extraction the effect is within run-to-run noise, the gap costs 6 MB per octave).
         const size_t stagger = px >= ((size_t)16 << 20) ? (size_t)1057024 : 0;
         for (int i = 0; i < nl + 3; ++i) { o_g[o][i] = take(px); (void)take(stagger); }
     }
@@ -1206,9 +1207,12 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             d_src = img;
             src_stride = stride;
             src_zs = img_pitch;
+        } else if (img_on_device) {
+            HIP_TRY(ctx, hipMemcpy2DAsync(d_img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyDeviceToDevice,
+                                          ctx->stream));
         } else {
-            HIP_TRY(ctx, hipMemcpy2DAsync(d_img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
-                                          img_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+            int rcu = imatch_stage_upload(ctx, img, h, w, stride, d_img);   // consumed before this call's synchronisation
+            if (rcu) return rcu;
         }
         if (P->clahe) {
             int rc = imatch_clahe_dev(ctx, d_src, h, w, src_stride, P->clahe_clip, P->clahe_tiles_x, P->clahe_tiles_y, d_clahe,
@@ -1276,7 +1280,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                 const int iw = cols - 2 * SIFT_IMG_BORDER, ih = rows - 2 * SIFT_IMG_BORDER;
                 if (nl == 3) {
                     const size_t px = (size_t)iw * ih * batch;
-                    const int rpw = px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
+                    const int rpw = px >= ((size_t)1 << 26) ? 64 : px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
                     hipLaunchKernelGGL(detect_stream_kernel,
                                        dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * rpw - 1) / (4 * rpw), batch), dim3(256), 0, st,
                                        T, o, rpw, thr, d_cand, cap, d_cnt, zs);

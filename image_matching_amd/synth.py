@@ -123,3 +123,38 @@ def synth_frame(map_img, i, size=(480, 640), scale_range=(0.8, 1.25)):
     f = warp_bilinear(map_img, H, h, w)
     f = f * rng.uniform(0.8, 1.2) + rng.uniform(-15, 15) + rng.normal(0, 3, size=f.shape)
     return np.clip(np.rint(f), 0, 255).astype(np.uint8), H / H[2, 2]
+
+
+def synth_flight(map_img, n, size=(720, 1280), map_pixel_size=0.5, frame_pixel_size=0.375, fps=5.0, speed=20.0, seed=0):
+    """A straight-ish flight over the map for the replay loop (BASELINE configs[2]: 1280x720 frames at the
+    reference's ~5 Hz publishing cadence, photo_publisher.py:110,130-131). Returns a list of (frame u8, truth)
+    with truth = dict(stamp, cx, cy: map pixel under the frame centre, yaw: frame rotation against the map,
+    H: frame pixel -> map pixel)."""
+    rng = np.random.default_rng(5000 + seed)
+    h, w = size
+    side_y, side_x = map_img.shape
+    s = frame_pixel_size / map_pixel_size
+    margin = 0.75 * s * np.hypot(h, w) * 2.2 + 16           # room for the search window around the frame
+    step = speed / fps / map_pixel_size                      # map pixels per frame
+    heading = rng.uniform(-np.pi, np.pi)
+    cx = rng.uniform(margin, side_x - margin)
+    cy = rng.uniform(margin, side_y - margin)
+    yaw = rng.uniform(-0.4, 0.4)
+    out = []
+    for i in range(n):
+        nx, ny = cx + step * np.cos(heading), cy + step * np.sin(heading)
+        if not (margin <= nx <= side_x - margin and margin <= ny <= side_y - margin):
+            heading += np.pi / 2 + rng.uniform(0, np.pi / 2)   # turn away from the border
+            nx, ny = cx + step * np.cos(heading), cy + step * np.sin(heading)
+            nx, ny = np.clip(nx, margin, side_x - margin), np.clip(ny, margin, side_y - margin)
+        cx, cy = nx, ny
+        heading += rng.normal(0, 0.02)
+        yaw = float(np.clip(yaw + rng.normal(0, 0.01), -0.5, 0.5))
+        c, sn = np.cos(yaw) * s, np.sin(yaw) * s
+        H = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1.0]]) @ np.array([[c, -sn, 0], [sn, c, 0], [0, 0, 1.0]]) @ \
+            np.array([[1, 0, -(w - 1) / 2], [0, 1, -(h - 1) / 2], [0, 0, 1.0]])
+        f = warp_bilinear(map_img, H, h, w)
+        f = f * rng.uniform(0.9, 1.1) + rng.uniform(-10, 10) + rng.normal(0, 3, size=f.shape)
+        out.append((np.clip(np.rint(f), 0, 255).astype(np.uint8),
+                    {"stamp": i / fps, "cx": float(cx), "cy": float(cy), "yaw": yaw, "H": H}))
+    return out

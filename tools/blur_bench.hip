@@ -51,6 +51,15 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed) {
     unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
     p[i] = (float)(h & 0xffff) * (255.f / 65535.f);
 }
+__global__ void fill_image(float* p, int cols, size_t n, unsigned seed) {   // textured, image-like content
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % cols), y = (int)(i / cols);
+    unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    float v = 127.f + 60.f * __sinf(x * 0.013f) * __cosf(y * 0.017f) + 40.f * __sinf((x + 2 * y) * 0.11f) + (float)(h & 15);
+    if (((x >> 7) + (y >> 6)) & 1) v *= 0.6f;
+    p[i] = fminf(fmaxf(rintf(v), 0.f), 255.f);
+}
 __global__ void fill_u8(uint8_t* p, size_t n, unsigned seed) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -190,12 +199,13 @@ static void one(const float* a, float* b, int n) {
     gauss(R, k);
     blur_march_launch<R, 64, false>(0, a, b, nullptr, n, n, 0, k, 1, 0, 0, 0);
 }
-static void pipeline(size_t gap_extra, bool sync_between) {
+static void pipeline(size_t gap_extra, bool sync_between, bool image_like = false) {
     const int n = 16384;
     const size_t px = (size_t)n * n, gap = px * 4 + gap_extra;
     char* arena;
     CK(hipMalloc(&arena, gap * 6));
-    hipLaunchKernelGGL(fill_f32, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, 0, (float*)arena, px, 3u);
+    if (image_like) hipLaunchKernelGGL(fill_image, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, 0, (float*)arena, n, px, 3u);
+    else hipLaunchKernelGGL(fill_f32, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, 0, (float*)arena, px, 3u);
     hipEvent_t e[6];
     for (auto& x : e) CK(hipEventCreate(&x));
     auto L = [&](int i) { return (float*)(arena + gap * i); };
@@ -210,6 +220,7 @@ static void pipeline(size_t gap_extra, bool sync_between) {
         CK(hipDeviceSynchronize());
         float t[5];
         for (int i = 0; i < 5; ++i) CK(hipEventElapsedTime(&t[i], e[i], e[i + 1]));
+        if (image_like) printf("image-like ");
         printf("pipeline gap 2^30+%zu %s: R5 %.3f  R6 %.3f  R8 %.3f  R10 %.3f  R13 %.3f ms\n", gap_extra,
                sync_between ? "host sync between" : "queued back to back", t[0], t[1], t[2], t[3], t[4]);
     }
@@ -223,6 +234,7 @@ int main(int argc, char** argv) {
         pipeline(0, false);
         pipeline((1 << 20) + 8192 + 256, true);
         pipeline((1 << 20) + 8192 + 256, false);
+        pipeline((1 << 20) + 8192 + 256, false, true);
         return 0;
     }
     const int n = 16384;
