@@ -230,12 +230,15 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
                 const int rowbase = s * TN + tile * 32 + 4 * h;
                 const float g = G[qb];
                 // all 16 results straight from the accumulator registers, branch-free selects
+                // (a register none of whose 64 results passes the bound is skipped with one compare and a scalar
+                // branch: usually one or two of the sixteen have a candidate)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const float v = a[reg];
+                    const bool pass = v >= g;
+                    if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
                     const float x = -2.0f * v;
                     const int idx = rowbase + (reg & 3) + 8 * (reg >> 2);
-                    const bool pass = v >= g;
                     const bool lt1 = pass && x < b1;
                     const bool lt2 = pass && !lt1 && x < b2;
                     b2 = lt1 ? b1 : (lt2 ? x : b2);
