@@ -1,0 +1,41 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): the round's bench line, rocprofv3 kernel-trace summaries and PMC passes.
+# Usage: tools/collect_profiles.sh <tag>     -> gpurun_out/<tag>/...
+set -o pipefail
+tag=${1:-r1}
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+step() { echo "== $*" >&2; }
+
+step bench
+timeout -k 10 600 python3 -u "$root/bench.py" > "$out/bench.json" 2> "$out/bench.err" || exit 1
+
+step kernel-trace bench
+timeout -k 10 400 rocprofv3 --kernel-trace -d "$out/kt_bench" -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline \
+    > "$out/kt_bench.json" 2> "$out/kt_bench.err" || exit 1
+python3 "$root/tools/rocpd_stats.py" "$out"/kt_bench/*/*_results.db "$out/bench_kernel_stats.md" > /dev/null || exit 1
+
+step kernel-trace map extraction
+timeout -k 10 400 rocprofv3 --kernel-trace -d "$out/kt_map" -- python3 "$root/tools/extract_profile.py" 8192 3 \
+    > "$out/kt_map.log" 2>&1 || exit 1
+python3 "$root/tools/rocpd_stats.py" "$out"/kt_map/*/*_results.db "$out/map_extract_kernel_stats.md" > /dev/null || exit 1
+python3 "$root/tools/rocpd_timeline.py" "$out"/kt_map/*/*_results.db 64 "$out/map_extract_timeline.md" > /dev/null || exit 1
+
+step pmc FETCH_SIZE
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline \
+    > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.err" || exit 1
+python3 "$root/tools/pmc_sum.py" "$out"/pmc_fetch/*/*_results.db "$out/pmc_fetch.md" > /dev/null || exit 1
+
+step pmc WRITE_SIZE
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline \
+    > "$out/pmc_write.json" 2> "$out/pmc_write.err" || exit 1
+python3 "$root/tools/pmc_sum.py" "$out"/pmc_write/*/*_results.db "$out/pmc_write.md" > /dev/null || exit 1
+
+step replay
+timeout -k 10 400 python3 "$root/tools/replay_c3.py" 240 8192 > "$out/replay_c3.json" 2> "$out/replay_c3.err" || exit 1
+
+# the .db files are large; keep the summaries
+rm -rf "$out"/kt_bench "$out"/kt_map "$out"/pmc_fetch "$out"/pmc_write
+echo done >&2
