@@ -11,11 +11,19 @@ through the batched entry points: extract (every kernel launched once for the ba
 over all the batch's keypoints against the whole map -> ratio -> homography per frame (iff > 10 good
 matches, position_finder.py:316). Per frame the results are identical to the single-frame entry points
 (tests/test_batch_gpu.py); --batch 1 runs those instead, and their latency is reported beside the
-headline as "single_frame". At N > 1 the map's descriptors are sharded over the ranks (contiguous index
-ranges), each rank extracts its OWN batch, queries are all-gathered, every rank matches all batches
-against its shard, and an all_to_all returns the per-shard top-2 to the batch's owner
-(image_matching_amd/sharded.py). Per-GPU work per step is constant, total frames per step = N * batch:
-"scaling": "weak". value = N * batch * steps / wall time, wall = max over ranks between two barriers.
+headline as "single_frame".
+
+At N > 1 every rank takes its OWN batches (frames are independent units: data-parallel, per-GPU work per step
+constant, total frames per step = N * batch: "scaling": "weak"; value = N * batch * steps / wall time, wall =
+max over ranks between two barriers). What happens to the map depends on its size (--map-mode):
+  replicated  a map whose descriptor set fits one GPU many times over (configs[1]'s does: 60 MB) lives on every
+              rank whole; no data-path collective (auto picks this below 16 GiB of packed descriptors);
+  sharded     the map's descriptors are split over the ranks by contiguous index ranges, queries are
+              all-gathered, every rank matches all batches against its shard, and an all_to_all returns the
+              per-shard top-2 to the batch's owner (image_matching_amd/sharded.py: the layout of configs[3]/[4],
+              maps of 5M-20M descriptors).
+In replicated mode a short sharded loop is run AFTER the timed region and reported beside the headline as
+"sharded_map" (its failure is reported there and does not touch `value`).
 
 One JSON line on stdout (rank 0). Progress goes to stderr."""
 import argparse
@@ -77,6 +85,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64,
                     help="frames per step and GPU, taken through the batched entry points (one launch per stage for "
                          "the whole batch, one kNN launch over all frames' keypoints); 1 = the single-frame calls")
+    ap.add_argument("--map-mode", choices=["auto", "replicated", "sharded"], default="auto",
+                    help="N > 1: whole map on every rank (no collective) or map rows sharded over the ranks (all_gather + "
+                         "all_to_all per step); auto = replicated when the packed descriptor set is below 16 GiB")
     ap.add_argument("--streams", type=int, default=1,
                     help="frames in flight per GPU: each has its own context (stream + arena) and host thread; a step is "
                          "then one frame per stream")
@@ -120,18 +131,27 @@ def main():
     map_xy = np.ascontiguousarray(map_kp[:, :2])
     log("[rank %d] map: %d descriptors, extract %.2fs (first) %.2fs (warm), scale-space stage %.2f ms"
         % (rank, n_map, t_map_extract, t_map_extract2, pyr_ms_map))
+    map_mode = args.map_mode
+    if map_mode == "auto":
+        map_mode = "replicated" if n_map * 264 < (16 << 30) else "sharded"
+    if world == 1:
+        map_mode = "replicated"
     lo, hi = sharded.partition(n_map, world)[rank]
+    f_shard = None
     if world > 1:
         all_u8 = torch.empty((n_map, 128), dtype=torch.uint8, device=dev)
         f_map.desc_u8_dev(all_u8.data_ptr())
         ctx.synchronize()
         shard_u8 = all_u8[lo:hi].contiguous()
         f_shard = ctx.features_from_device_u8(shard_u8.data_ptr(), hi - lo)
-        f_map.free()
         del all_u8
+    if map_mode == "replicated":
+        matcher = sharded.ShardedMatcher(ctx, f_map, 0, dev, local_only=True)
+        n_local = n_map
     else:
-        f_shard = f_map
-    matcher = sharded.ShardedMatcher(ctx, f_shard, lo, dev)
+        matcher = sharded.ShardedMatcher(ctx, f_shard, lo, dev)
+        n_local = hi - lo
+    f_local = f_map if map_mode == "replicated" else f_shard
 
     # ---- frames: each rank has its own set, resident in HBM before the timed region
     frames_h = [synth.synth_frame(map_img, 100 * rank + i, size=(480, 640))[0] for i in range(args.frames)]
@@ -148,7 +168,8 @@ def main():
     ctxs = [ctx] + [im.Context(local_rank) for _ in range(n_streams - 1)]
     for c in ctxs[1:]:
         c.set_profiling(True)
-    matchers = [matcher] + [sharded.ShardedMatcher(c, f_shard, lo, dev) for c in ctxs[1:]]
+    matchers = [matcher] + [sharded.ShardedMatcher(c, f_local, 0 if map_mode == "replicated" else lo, dev,
+                                                    local_only=map_mode == "replicated") for c in ctxs[1:]]
     import threading
     stats_lock = threading.Lock()
 
@@ -179,14 +200,14 @@ def main():
 
     # batched steps: B frames resident as one [B,480,640] tensor per step
     B = max(1, args.batch)
-    bq_cap = ((B * 3584 + 1023) // 1024) * 1024      # rows per batch in the exchange / result buffers
+    bq_cap = ((B * 3200 + 1023) // 1024) * 1024      # rows per batch in the exchange / result buffers (frames: ~2940 each)
     if B > 1:
         n_sets = max(2, (len(frames_h) + B - 1) // B)
         batches_d = [torch.from_numpy(np.stack([frames_h[(j * B + k) % len(frames_h)] for k in range(B)])).to(dev)
                      for j in range(n_sets)]
 
-    def step_batch(i, record=False, lane=0):
-        cx, mt = ctxs[lane], matchers[lane]
+    def step_batch(i, record=False, lane=0, mt=None):
+        cx, mt = ctxs[lane], (mt if mt is not None else matchers[lane])
         fr = batches_d[(i * n_streams + lane) % len(batches_d)]
         f, offs = cx.sift_extract_batch_dev(fr.data_ptr(), B, 480 * 640, 480, 640, 640, params)
         nq = len(f)
@@ -258,6 +279,28 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
 
+    # N > 1, replicated map: the sharded-map exchange path, outside the timed region
+    sharded_extra = None
+    if world > 1 and map_mode == "replicated" and B > 1:
+        try:
+            mt_sh = sharded.ShardedMatcher(ctx, f_shard, lo, dev)
+            n_sh = 10
+            for i in range(2):
+                step_batch(i, False, 0, mt_sh)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(n_sh):
+                step_batch(i, False, 0, mt_sh)
+            barrier()
+            tw = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            sharded_extra = {"frames_per_s": world * B * n_sh / float(tw.item()), "ms_per_step": float(tw.item()) / n_sh * 1e3,
+                             "steps": n_sh, "knn_launch_ms": ctx.knn2_kernel_ms(),
+                             "per_launch": "%d query rows (all ranks' batches, padded) x %d shard rows" % (world * bq_cap, hi - lo),
+                             "exchange": "all_gather of u8 query rows + all_to_all of per-shard top-2 (RCCL), merge_top2"}
+        except Exception as e:    # must not take the headline down with it
+            sharded_extra = {"error": repr(e)[:300]}
+
     # single-frame latency, outside the timed region: the per-frame calls, one frame at a time
     single_ms = None
     if world == 1:
@@ -274,9 +317,9 @@ def main():
         fps = world * n_streams * B * args.steps / wall
         q_mean = float(np.mean(stats["kp"]))
         knn_ms = float(np.mean(stats["knn_ms"]))
-        n_local = hi - lo
         cap_rows = bq_cap if B > 1 else q_cap
-        q_per_launch = (world * cap_rows) if world > 1 else q_mean    # one launch holds all B frames' keypoints
+        exchange = world > 1 and map_mode == "sharded"
+        q_per_launch = (world * cap_rows) if exchange else q_mean     # one launch holds all B frames' keypoints
         flops = 256.0 * q_per_launch * n_local            # 256 flop per (query, train) pair
         achieved_tf = flops / (knn_ms * 1e-3) / 1e12
         pyr_bytes = PYRAMID_BYTES_PER_INPUT_PIXEL * args.map_side * args.map_side
@@ -294,9 +337,10 @@ def main():
                        "good_matches_per_frame": float(np.mean(stats["good"])),
                        "homographies_found": "%d/%d" % (stats["found"], args.steps * B * n_streams), "ratio": ratio,
                        "frames_in_flight_per_gpu": n_streams,
-                       "parallelism": "map sharded x%d, frames data-parallel" % world if world > 1 else "single GPU"},
-            "knn_gdist_per_s": world * q_mean * n_map / (knn_ms * 1e-3) / 1e9 if world == 1
-                               else world * cap_rows * float(n_local) * world / (knn_ms * 1e-3) / 1e9,
+                       "parallelism": "single GPU" if world == 1 else
+                                      ("map sharded x%d, frames data-parallel" % world if exchange else
+                                       "map replicated on %d GPUs, frames data-parallel, no collective" % world)},
+            "knn_gdist_per_s": world * q_per_launch * float(n_local) / (knn_ms * 1e-3) / 1e9,
             "roofline": {"kernel": "knn2_kernel (bf16 MFMA, fused top-2)", "bound": "mfma", "achieved": achieved_tf,
                          "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_BF16_PEAK_TF,
                          "traffic": None, "launch_ms": knn_ms,
@@ -318,6 +362,8 @@ def main():
                 out["roofline"]["traffic_note"] = "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE, " + pmc["source"]
         except (OSError, ValueError, KeyError):
             pass
+        if sharded_extra is not None:
+            out["sharded_map"] = sharded_extra
         if single_ms is not None:
             out["single_frame"] = {"ms_per_frame": single_ms, "frames_per_s": 1e3 / single_ms,
                                    "note": "one frame at a time through the single-frame entry points, measured after "
@@ -325,7 +371,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
             n_s = min(n_map, 100_000)
-            d_s = f_shard.download(keypoints=False)[1][:n_s].astype(np.uint8)
+            d_s = f_local.download(keypoints=False)[1][:n_s].astype(np.uint8)
             out["cpu_baseline"] = cpu_baseline(frames_h[0], d_s, n_map, map_xy[:n_s], ratio, threads)
         else:
             out["cpu_baseline"] = None

@@ -44,16 +44,17 @@ class _StreamScope:
 
 
 class ShardedMatcher:
-    def __init__(self, backend, shard_features, global_offset, device, group=None):
+    def __init__(self, backend, shard_features, global_offset, device, group=None, local_only=False):
         """backend: an image_matching_amd.Context (or an object with the same knn2_dev / merge_top2_dev /
-        features_from_device_u8 / synchronize methods); shard_features: this rank's rows of the map."""
+        features_from_device_u8 / synchronize methods); shard_features: this rank's rows of the map.
+        local_only: the rank holds the WHOLE map (a map that fits one GPU is replicated, not sharded): no exchange."""
         self.backend = backend
         self.shard = shard_features
         self.offset = int(global_offset)
         self.device = torch.device(device)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() and not local_only else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() and not local_only else 0
         self._bufs = {}
 
     def _buf(self, name, shape, dtype):

@@ -103,7 +103,11 @@ def _worker(rank, world, port, ret):
         ridx2, rdist2 = oracle.knn2(mine, train)
         ok_dp = np.array_equal(out2[:, [1, 3]], ridx2) and np.array_equal(
             np.sqrt(out2[:, [0, 2]].astype(np.float32)), rdist2)
-        ret[rank] = (bool(ok_rep), bool(ok_dp), out2.shape[0])
+        # a map that fits one GPU is replicated: the whole set on every rank, no exchange (bench.py --map-mode replicated)
+        m_rep = sharded.ShardedMatcher(be, be.features(train), 0, "cpu", local_only=True)
+        out3 = m_rep.match_dp(be.features(mine), len(mine), q_cap=256).numpy().copy()
+        ok_local = m_rep.world == 1 and np.array_equal(out3, out2)
+        ret[rank] = (bool(ok_rep), bool(ok_dp and ok_local), out2.shape[0])
     finally:
         dist.destroy_process_group()
 
