@@ -53,7 +53,11 @@ def make_map(img, pixel_size, lat0=55.0, lon0=37.0):
 
 
 class PositionFinder:
-    def __init__(self, main_map, matcher=None, config=None):
+    def __init__(self, main_map, matcher=None, config=None, map_roi=None):
+        """map_roi: the whole map as one resident `roi` (mapdb.MapDB.as_roi). When given, find_pose matches every frame
+        against it instead of cropping and re-extracting ROIs (no counterpart in the reference, whose ROI features are
+        re-extracted every 12th frame)."""
+        self.map_roi = map_roi
         cfg = dict(DEFAULT_CONFIG)
         cfg.update(config or {})
         self.main_map = main_map
@@ -136,6 +140,8 @@ class PositionFinder:
 
     # ---- find_pose (position_finder.py:226-290) --------------------------------------------------------
     def find_pose(self, cadr):
+        if self.map_roi is not None:
+            return self.pose_from_roi(self.map_roi, cadr)
         if self.first_cadr is True:
             if self.use_gps is True:
                 if self.roi_iterator > 10:

@@ -152,3 +152,28 @@ def test_synthetic_flight_fixes_match_truth(ctx):
     # scale, and solve_IK ignores the half-pixel of the area resize (utils.py:17-22, match_finder.py:165-175,257-275)
     assert np.median(err) < 0.75 and err.max() < 1.0, err
     assert all(1000 < f["cadr_kp"] < 6000 for f in pf.frames)
+
+
+@pytest.mark.gpu
+def test_flight_against_the_resident_map_database(ctx):
+    """The same loop with the map's features extracted once and resident (mapdb.MapDB.as_roi): no ROI extraction at all,
+    every frame matched against the whole map, fixes in full-map pixels."""
+    from image_matching_amd.mapdb import MapDB
+    from image_matching_amd.match_finder import match_finder
+    m = synth.synth_map(4096, seed=99)
+    flight = synth.synth_flight(m, 16, map_pixel_size=0.5, frame_pixel_size=0.375, seed=3)
+    mf = match_finder(ctx)
+    mf.draw_matches = False
+    main_map = replay.make_map(m, 0.5)
+    db = MapDB.build(ctx, m, tile=2048, margin=256, pixel_size=0.5)
+    poi = replay.DEFAULT_CONFIG["camera_poi"] / 180.0 * np.pi
+    pf = replay.PositionFinder(main_map, mf, {"height": 0.375 * 1280 / (2 * np.tanh(poi / 2)), "low_pass_coordinates": 1e6},
+                               map_roi=db.as_roi(ctx, main_map))
+    for img, tr in flight:
+        pf.photo_cb(img, imu=(0.0, 0.0, tr["yaw"]), stamp=tr["stamp"])
+    assert pf.calls["roi_extract"] == 0 and pf.calls["frame_extract"] == 16 and len(pf.fixes) == 16, pf.errors[:3]
+    truth = {tr["stamp"]: tr for _, tr in flight}
+    err = np.array([np.hypot(f["x_m"] - truth[f["stamp"]]["cx"] * 0.5, f["y_m"] - truth[f["stamp"]]["cy"] * 0.5)
+                    for f in pf.fixes])
+    assert err.max() < 0.5, err            # 1 map pixel
+    db.release()

@@ -30,8 +30,17 @@ g = replay.GeodeticConvert()
 g.initialiseReference(main_map.main_points[0].lat, main_map.main_points[0].lon, 0)
 
 
+map_roi = None
+if os.environ.get("REPLAY_MAPDB"):          # every frame against the whole resident map instead of ROI crops
+    from image_matching_amd.mapdb import MapDB
+    t0 = time.perf_counter()
+    db = MapDB.build(mf.ctx, m, tile=4096, margin=256, pixel_size=map_px)
+    print("map database: %d descriptors in %.2f s" % (len(db), time.perf_counter() - t0), file=sys.stderr)
+    map_roi = db.as_roi(mf.ctx, main_map)
+
+
 def run(frames):
-    pf = replay.PositionFinder(main_map, mf, {"height": height, "low_pass_coordinates": lowpass})
+    pf = replay.PositionFinder(main_map, mf, {"height": height, "low_pass_coordinates": lowpass}, map_roi=map_roi)
     t0 = time.perf_counter()
     for img, tr in frames:
         lat, lon, _ = g.ned2Geodetic(north=-tr["cy"] * map_px, east=tr["cx"] * map_px, down=0)
@@ -57,6 +66,7 @@ print(json.dumps({
     "ms_per_frame": wall / n * 1e3, "fixes": len(pf.fixes), "fix_rate": len(pf.fixes) / n,
     "position_error_m": {"median": float(np.median(err)) if err else None, "p90": float(np.percentile(err, 90)) if err else None,
                          "max": float(np.max(err)) if err else None, "map_pixel_m": map_px},
+    "roi_source": "resident map database (whole map)" if map_roi is not None else "crop around the last fix, re-extracted every 12th frame",
     "calls": pf.calls, "odometry_ticks": len(pf.odometry), "swallowed_errors": len(pf.errors),
     "mean_keypoints": {"frame": float(np.mean([f["cadr_kp"] for f in pf.frames])), "roi": float(np.mean([f["roi_kp"] for f in pf.frames]))},
 }))
