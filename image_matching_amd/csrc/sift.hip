@@ -858,6 +858,7 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
     const int n_kp = seg.off[blockIdx.z + 1] - seg.off[blockIdx.z];
     constexpr int GROUPS = 4 / WPK, GL = 64 * WPK;
     __shared__ unsigned long long hist[GROUPS][DESC_HIST];
+    __shared__ unsigned queue[4][128];   // per wave: indices of samples inside the rotated grid, waiting for a full wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x / GL, gl = threadIdx.x % GL;
     const int id = blockIdx.x * GROUPS + wave;
     for (int i = gl; i < DESC_HIST; i += GL) hist[wave][i] = 0ull;
@@ -903,43 +904,77 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
         const unsigned step = (unsigned)(((unsigned long long)GL * (unsigned)spread) % (unsigned)total);
         unsigned p = (unsigned)(((unsigned long long)gl * (unsigned)spread) % (unsigned)total);
         const float inv_side = 1.0f / (float)side;
-        for (int q = gl; q < total; q += GL) {
-            const int pi = (int)(((float)p + 0.5f) * inv_side);
-            const int i = pi - radius, j = (int)p - pi * side - radius;
-            p += step;
-            if (p >= (unsigned)total) p -= (unsigned)total;
+        // About half of the square's samples fall outside the rotated 4x4 grid. Testing and accumulating in one
+        // loop leaves those lanes idle through the ~200 instructions of the accumulation; instead every wave
+        // QUEUES the samples that pass the test (their index p, slots from ballot prefix counts) and runs the
+        // accumulation on 64 queued samples at a time, all lanes busy. The fixed-point sums do not depend on the order.
+        unsigned* const wq = queue[threadIdx.x >> 6];
+        int n_q = 0;   // wave-uniform
+        auto accumulate = [&](unsigned ps) {
+            const int pi = (int)(((float)ps + 0.5f) * inv_side);
+            const int i = pi - radius, j = (int)ps - pi * side - radius;
             const float c_rot = j * cos_t - i * sin_t;
             const float r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f;
             float cbin = c_rot + d / 2 - 0.5f;
-            const int r = py + i, c = px + j;
-            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1) {
-                const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1];
-                const float dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
-                const float w = expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-                float obin = (atan2_deg(dy, dx) - ori) * bins_per_rad;
-                const float mag = sqrtf(dx * dx + dy * dy) * w;
-                const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
-                int o0 = (int)floorf(obin);
-                rbin -= r0; cbin -= c0; obin -= o0;
-                if (o0 < 0) o0 += n;
-                if (o0 >= n) o0 -= n;
-                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
-                const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-                const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
-                const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-                const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
-                const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-                const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-                unsigned long long* hp = hist[wave];
+            const unsigned at = (unsigned)(py + i) * (unsigned)cols + (unsigned)(px + j);   // below 2^30 elements
+            const float dx = img[at + 1] - img[at - 1];
+            const float dy = img[at - (unsigned)cols] - img[at + (unsigned)cols];
+            const float w = expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            float obin = (atan2_deg(dy, dx) - ori) * bins_per_rad;
+            const float mag = sqrtf(dx * dx + dy * dy) * w;
+            const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+            int o0 = (int)floorf(obin);
+            rbin -= r0; cbin -= c0; obin -= o0;
+            if (o0 < 0) o0 += n;
+            if (o0 >= n) o0 -= n;
+            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+            const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+            const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+            const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+            const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+            unsigned long long* hp = hist[wave];
 #define HADD(off, val) atomicAdd(&hp[idx + (off)], (unsigned long long)(long long)__float2int_rn((val) * FIX_SCALE))
-                HADD(0, v_rco000); HADD(1, v_rco001);
-                HADD(n + 2, v_rco010); HADD(n + 3, v_rco011);
-                HADD((d + 2) * (n + 2), v_rco100); HADD((d + 2) * (n + 2) + 1, v_rco101);
-                HADD((d + 3) * (n + 2), v_rco110); HADD((d + 3) * (n + 2) + 1, v_rco111);
+            HADD(0, v_rco000); HADD(1, v_rco001);
+            HADD(n + 2, v_rco010); HADD(n + 3, v_rco011);
+            HADD((d + 2) * (n + 2), v_rco100); HADD((d + 2) * (n + 2) + 1, v_rco101);
+            HADD((d + 3) * (n + 2), v_rco110); HADD((d + 3) * (n + 2) + 1, v_rco111);
 #undef HADD
+        };
+        for (int q0 = 0; q0 < total; q0 += GL) {      // wave-uniform trip count
+            const int q = q0 + gl;
+            bool ok = q < total;
+            if (ok) {
+                const int pi = (int)(((float)p + 0.5f) * inv_side);
+                const int i = pi - radius, j = (int)p - pi * side - radius;
+                const float c_rot = j * cos_t - i * sin_t;
+                const float r_rot = j * sin_t + i * cos_t;
+                const float rbin = r_rot + d / 2 - 0.5f;
+                const float cbin = c_rot + d / 2 - 0.5f;
+                const int r = py + i, c = px + j;
+                ok = rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1;
             }
+            const unsigned long long mk = __ballot(ok);
+            if (ok) wq[n_q + __popcll(mk & ((1ull << lane) - 1ull))] = p;
+            n_q += __popcll(mk);
+            p += step;
+            if (p >= (unsigned)total) p -= (unsigned)total;
+            if (n_q >= 64) {
+                wave_lds_fence();
+                const unsigned ps = wq[lane];
+                const unsigned carry = lane < n_q - 64 ? wq[64 + lane] : 0;
+                wave_lds_fence();
+                if (lane < n_q - 64) wq[lane] = carry;
+                n_q -= 64;
+                accumulate(ps);
+            }
+        }
+        if (n_q > 0) {
+            wave_lds_fence();
+            if (lane < n_q) accumulate(wq[lane]);
         }
     }
     __syncthreads();
