@@ -98,9 +98,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal aids for a one-GPU box (never set by the driver): IMATCH_BENCH_DEVICE puts every rank on that device,
+    # IMATCH_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one GPU.
+    backend = os.environ.get("IMATCH_BENCH_BACKEND", "nccl")
+    if "IMATCH_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["IMATCH_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world:
         log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
@@ -285,6 +293,16 @@ def main():
         try:
             mt_sh = sharded.ShardedMatcher(ctx, f_shard, lo, dev)
             n_sh = 10
+            # the exchange path must give what the whole map gives: one batch through both, compared bit for bit
+            f_chk, _ = ctx.sift_extract_batch_dev(batches_d[0].data_ptr(), B, 480 * 640, 480, 640, 640, params)
+            a = matcher.match_dp(f_chk, len(f_chk), bq_cap)
+            ctx.synchronize()
+            a = a.clone()
+            b = mt_sh.match_dp(f_chk, len(f_chk), bq_cap)
+            ctx.synchronize()
+            same = torch.tensor([int(torch.equal(a, b))], dtype=torch.int64, device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            f_chk.free()
             for i in range(2):
                 step_batch(i, False, 0, mt_sh)
             barrier()
@@ -297,7 +315,8 @@ def main():
             sharded_extra = {"frames_per_s": world * B * n_sh / float(tw.item()), "ms_per_step": float(tw.item()) / n_sh * 1e3,
                              "steps": n_sh, "knn_launch_ms": ctx.knn2_kernel_ms(),
                              "per_launch": "%d query rows (all ranks' batches, padded) x %d shard rows" % (world * bq_cap, hi - lo),
-                             "exchange": "all_gather of u8 query rows + all_to_all of per-shard top-2 (RCCL), merge_top2"}
+                             "exchange": "all_gather of u8 query rows + all_to_all of per-shard top-2 (RCCL), merge_top2",
+                             "identical_to_whole_map": bool(same.item())}
         except Exception as e:    # must not take the headline down with it
             sharded_extra = {"error": repr(e)[:300]}
 
