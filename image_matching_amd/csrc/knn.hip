@@ -227,7 +227,10 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
                 float* sq = st + qb * 256;
                 float b1 = sq[lane], b2 = sq[64 + lane];
                 int i1 = __float_as_int(sq[128 + lane]), i2 = __float_as_int(sq[192 + lane]);
-                const int rowbase = s * TN + tile * 32 + 4 * h;
+                // (the empty asm pins the row numbers to this path: the compiler otherwise computes all sixteen of them
+                // before the branch, on every block, which was 40 % of the hot path's vector instructions)
+                int rowbase = s * TN + tile * 32 + 4 * h;
+                asm volatile("" : "+v"(rowbase));
                 const float g = G[qb];
                 // all 16 results straight from the accumulator registers, branch-free selects
                 // (a register none of whose 64 results passes the bound is skipped with one compare and a scalar
