@@ -92,3 +92,34 @@ class DeviceDescriptors:
 
     def __getitem__(self, i):
         return self.__array__()[i]
+
+
+
+class GoodMatches:
+    """The `good` list find_matches returns -- [[DMatch], [DMatch], ...] (match_finder.py:191-194) -- backed by three
+    arrays. len(), indexing and iteration behave like the list of one-element lists the reference builds (its callers
+    use len(good) and m[0].queryIdx / m[0].trainIdx: position_finder.py:316, match_finder.py:231-232); the DMatch
+    objects are made when somebody reads them, and find_keypoints_transform reads the arrays directly."""
+
+    def __init__(self, query_idx, train_idx, distance):
+        self.query_idx = np.ascontiguousarray(query_idx, dtype=np.int64)
+        self.train_idx = np.ascontiguousarray(train_idx, dtype=np.int64)
+        self.distance = np.ascontiguousarray(distance, dtype=np.float32)
+
+    def __len__(self):
+        return self.query_idx.shape[0]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return GoodMatches(self.query_idx[i], self.train_idx[i], self.distance[i])
+        return [DMatch(int(self.query_idx[i]), int(self.train_idx[i]), 0, float(self.distance[i]))]
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __repr__(self):
+        return "GoodMatches(%d)" % len(self)

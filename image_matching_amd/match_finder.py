@@ -21,7 +21,7 @@ import numpy as np
 
 from . import draw
 from ._lib import SiftParams
-from .cvtypes import DeviceDescriptors, DMatch, KeyPoints
+from .cvtypes import DeviceDescriptors, GoodMatches, KeyPoints
 from .geodetic_conv import GeodeticConvert
 from .params import get_param
 from .utils import default_context, isConvex, line_intersection, resize_img
@@ -174,12 +174,12 @@ class match_finder():
         # Lowe ratio in the reference's float semantics: f32 distances widened to double (match_finder.py:193)
         keep = dist[:, 0].astype(np.float64) < self.points_quality * dist[:, 1].astype(np.float64)
         q = np.nonzero(keep)[0]
-        good = [[DMatch(int(i), int(idx[i, 0]), 0, float(dist[i, 0]))] for i in q]
+        good = GoodMatches(q, idx[q, 0], dist[q, 0])     # [[DMatch], ...] when read; see cvtypes.GoodMatches
         img3 = None
         if self.draw_matches:
             img3 = draw.matches_canvas(cadr.img, cadr.kp.xy if hasattr(cadr.kp, "xy") else _xy(cadr.kp),
                                        roi.img, roi.kp.xy if hasattr(roi.kp, "xy") else _xy(roi.kp),
-                                       [(m[0].queryIdx, m[0].trainIdx) for m in good])
+                                       list(zip(good.query_idx.tolist(), good.train_idx.tolist())))
         return good, img3
 
     def find_keypoints_transform(self, matches, roi, cadr, img_for_pub):
@@ -187,8 +187,11 @@ class match_finder():
         kp1, kp2 = cadr.kp, roi.kp
         xy1 = kp1.xy if hasattr(kp1, "xy") else _xy(kp1)
         xy2 = kp2.xy if hasattr(kp2, "xy") else _xy(kp2)
-        qi = np.fromiter((m[0].queryIdx for m in matches), dtype=np.int64, count=len(matches))
-        ti = np.fromiter((m[0].trainIdx for m in matches), dtype=np.int64, count=len(matches))
+        if isinstance(matches, GoodMatches):
+            qi, ti = matches.query_idx, matches.train_idx
+        else:   # a plain list of [DMatch], as cv2 code would hand over
+            qi = np.fromiter((m[0].queryIdx for m in matches), dtype=np.int64, count=len(matches))
+            ti = np.fromiter((m[0].trainIdx for m in matches), dtype=np.int64, count=len(matches))
         src_pts = np.float32(xy1[qi]).reshape(-1, 1, 2)
         dst_pts = np.float32(xy2[ti]).reshape(-1, 1, 2)
         M, mask = self.ctx.homography(src_pts, dst_pts, self.homography_threshold, self.homography_seed)

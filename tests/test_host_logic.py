@@ -118,3 +118,14 @@ def test_roi_policy_host_logic():
     assert (r.pixel_x_main_map, r.pixel_y_main_map) == (0, 0) and r.img.shape == (1000, 1240)
     s, bigger = match_finder.find_scale(mf, Decimal("0.5"), Decimal("0.25"))
     assert bigger is True and s == Decimal("0.5")
+
+
+def test_good_matches_reads_like_the_reference_list():
+    """find_matches returns [[DMatch], ...] (reference match_finder.py:191-194); GoodMatches keeps it in arrays and
+    must read the same: len, index, iteration, m[0].queryIdx / .trainIdx / .distance."""
+    from image_matching_amd.cvtypes import DMatch, GoodMatches
+    g = GoodMatches([3, 7, 9], [100, 5, 42], [1.5, 2.25, 0.0])
+    assert len(g) == 3 and len(g[1]) == 1 and isinstance(g[1][0], DMatch)
+    assert [(m[0].queryIdx, m[0].trainIdx, m[0].distance, m[0].imgIdx) for m in g] == [(3, 100, 1.5, 0), (7, 5, 2.25, 0), (9, 42, 0.0, 0)]
+    assert len(g[1:]) == 2 and g[1:][0][0].queryIdx == 7
+    assert len(GoodMatches([], [], [])) == 0 and list(GoodMatches([], [], [])) == []
