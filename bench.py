@@ -225,10 +225,9 @@ def main():
         out4 = mt.match_dp(f, nq, bq_cap)
         gq, gt, gd, goff = cx.ratio_batch_dev(out4.data_ptr(), offs, ratio)
         knn_ms = cx.knn2_kernel_ms() if record else 0.0
-        kp = f.download(descriptors=False)[0]
         ng = np.diff(goff)
         use = ng > 10                                      # position_finder.py:316
-        src = kp[np.repeat(offs[:-1], ng) + gq, :2]
+        src = f.keypoints_xy(np.repeat(offs[:-1], ng) + gq)
         src_off = goff
         gt_u = gt
         if not use.all():                                  # frames below the gate take no part

@@ -69,6 +69,7 @@ SIGNATURES = {
                                                ctypes.POINTER(ctypes.c_int)]),
     "imatch_features_desc_u8_dev": (ctypes.c_int, [c_vp, c_vp]),
     "imatch_features_download": (ctypes.c_int, [c_vp, c_f32p, c_f32p]),
+    "imatch_features_keypoints_xy": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, c_f32p]),
     "imatch_features_image": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int]),
     "imatch_sift_debug_layer": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
                                                ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
@@ -137,6 +138,15 @@ class Features:
             self.ctx._check(self.ctx.lib.imatch_features_download(
                 self._h, _ptr(kp, c_f32p) if keypoints else None, _ptr(desc, c_f32p) if descriptors else None))
         return kp, desc
+
+    def keypoints_xy(self, rows):
+        """-> float32 [n,2]: (x, y) of the given keypoint rows (kp[m.queryIdx].pt of match_finder.py:231-232)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty((len(rows), 2), np.float32)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.imatch_features_keypoints_xy(
+                self._h, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(rows), _ptr(out, c_f32p)))
+        return out
 
     def desc_u8_dev(self, out_ptr):
         with self.ctx.lock:

@@ -28,6 +28,10 @@
 #include <thread>
 #include <vector>
 
+#include <chrono>
+static inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 #define MAX_OCT 16
 #define MAX_LAY 8
 #define SIFT_IMG_BORDER 5
@@ -1396,7 +1400,10 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         HIP_TRY(ctx, hipMemcpy2DAsync(h_cnt, 16, d_cnt, zs, 16, (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), d_kp, zs, (size_t)kp_hint * sizeof(KpRec),
                                       (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
+        const bool timing = getenv("IMATCH_TIMING") != nullptr;
+        const double t_a = now_ms();
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const double t_b = now_ms();
         int max_cand = 0, max_ref = 0, max_kp = 0;
         for (int b = 0; b < batch; ++b) {
             max_cand = std::max(max_cand, h_cnt[4 * b]);
@@ -1463,6 +1470,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             std::vector<KpRec> kps;
             for (int b = 0; b < batch; ++b) finish_image(b, kps);
         }
+        const double t_c = now_ms();
         int max_k = 0;
         for (int b = 0; b < batch; ++b) {
             seg.off[b + 1] = seg.off[b] + K_of[b];
@@ -1481,6 +1489,10 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                 p[5] = (float)rec[i].octave; p[6] = -1.f;
             }
         }
+        const double t_d = now_ms();
+        if (timing)
+            fprintf(stderr, "[imatch] extract host phases: wait for GPU %.3f ms, sort %.3f ms, alloc + keypoint table %.3f ms\n",
+                    t_b - t_a, t_c - t_b, t_d - t_c);
         if (offsets)
             for (int b = 0; b <= batch; ++b) offsets[b] = seg.off[b];
         if (P->clahe && batch == 1) {
@@ -1536,6 +1548,17 @@ int imatch_sift_extract_batch_dev(imatch_ctx* ctx, const uint8_t* img_dev, int n
     if (img_pitch < (size_t)stride * (size_t)(h > 0 ? h : 0) && n_img > 1)
         return imatch_set_err(ctx, IMATCH_EINVAL, "image pitch smaller than one image");
     return sift_extract(ctx, img_dev, 1, n_img, img_pitch, h, w, stride, P, out, offsets);
+}
+
+int imatch_features_keypoints_xy(const imatch_features* f, const int64_t* rows, int64_t n, float* out_xy) {
+    if (!f || n < 0 || (n > 0 && (!rows || !out_xy))) return IMATCH_EINVAL;
+    if (n > 0 && !f->kp) return imatch_set_err(f->ctx, IMATCH_EINVAL, "this descriptor set carries no keypoints");
+    for (int64_t i = 0; i < n; ++i) {
+        if (rows[i] < 0 || rows[i] >= f->n) return imatch_set_err(f->ctx, IMATCH_EINVAL, "keypoint row %lld of %lld", (long long)rows[i], (long long)f->n);
+        out_xy[2 * i] = f->kp[7 * rows[i]];
+        out_xy[2 * i + 1] = f->kp[7 * rows[i] + 1];
+    }
+    return IMATCH_OK;
 }
 
 int imatch_features_download(const imatch_features* f, float* kp, float* desc) {

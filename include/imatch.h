@@ -113,10 +113,13 @@ int imatch_sift_extract_batch_dev(imatch_ctx* ctx, const uint8_t* img_dev, int n
  * order: sorted and de-duplicated as KeyPointsFilter::removeDuplicatedSorted leaves them);
  * desc: [K][128] f32, integer valued 0..255. Either pointer may be null. */
 int imatch_features_download(const imatch_features* f, float* kp, float* desc);
+/* (x, y) of the keypoints rows[0..n): what the reference gathers for findHomography with
+ * `kp[m.queryIdx].pt` (MF:231-232), without copying the whole keypoint table. out_xy: [n][2] f32. */
+int imatch_features_keypoints_xy(const imatch_features* f, const int64_t* rows, int64_t n, float* out_xy);
 /* The image find_kp_dp returns (MF:221): the CLAHE output, [h][w] u8. */
 int imatch_features_image(const imatch_features* f, uint8_t* out, int h, int w);
 /* Test hook (no reference counterpart): copies one pyramid layer of the context's LAST extraction
- * to the host. kind 0 = Gaussian layer i of octave o, 1 = DoG layer. rows/cols receive its size;
+ * to the host. kind 0 = Gaussian layer i of octave o, 1 = DoG layer (gauss[i+1] - gauss[i], formed on the host: DoG layers are not stored). rows/cols receive its size;
  * out may be null to query the size only. */
 int imatch_sift_debug_layer(imatch_ctx* ctx, int kind, int o, int i, float* out, int* rows, int* cols);
 int imatch_sift_debug_octaves(imatch_ctx* ctx);

@@ -25,6 +25,10 @@ def test_extract_batch_equals_single(ctx, scene, clahe):
     params = im.SiftParams(clahe=clahe)
     f, offs = ctx.sift_extract_batch_dev(stack.data_ptr(), len(frames), 240 * 320, 240, 320, 320, params)
     kp, desc = f.download()
+    rows = np.array([0, len(f) - 1, len(f) // 2, 0], dtype=np.int64)
+    assert np.array_equal(f.keypoints_xy(rows), kp[rows, :2])          # the gather findHomography's caller makes (MF:231-232)
+    with pytest.raises(Exception):
+        f.keypoints_xy([len(f)])
     assert offs[0] == 0 and offs[-1] == len(f) and np.all(np.diff(offs) > 50)
     for b, fr in enumerate(frames):
         one = ctx.sift_extract(fr, params)
