@@ -25,6 +25,7 @@ struct imatch_ctx {
     hipEvent_t ev2, ev3;   // SIFT scale-space stage (upsample .. last extrema scan)
     // SIFT pyramid arena of the last extraction (kept for reuse by the next frame of the same size)
     struct imatch_sift_state* sift;
+    struct imatch_workers* workers;   // host worker pool, created on first use
     // device blocks handed out by imatch_pool_alloc; freed blocks are kept for the next call
     struct imatch_pool_block* pool;
     int pool_n, pool_cap;
@@ -72,6 +73,14 @@ void* imatch_pool_alloc(imatch_ctx* ctx, size_t bytes);
 void imatch_pool_free(imatch_ctx* ctx, void* p);
 void imatch_pool_destroy(imatch_ctx* ctx);
 int imatch_hs_reserve(imatch_ctx* ctx, size_t bytes);
+// Host worker pool (core.hip): runs fn(i) for i in [0, n) on up to 16 persistent threads of the context and returns
+// when all are done. The per-image sorts of a batch and the per-frame homography refits use it: spawning 16
+// std::threads per call cost about as much as the work itself.
+#ifdef __cplusplus
+#include <functional>
+void imatch_parallel_for(imatch_ctx* ctx, int n, const std::function<void(int)>& fn);
+void imatch_workers_destroy(imatch_ctx* ctx);
+#endif
 // Host images are pageable numpy memory: an asynchronous 2-D copy from it degenerates into one small
 // transfer per row (6 ms for a 1280x720 frame). The rows are packed into a pinned block first and go up
 // in one transfer; a download lands in the block's second part and is copied out after the caller's

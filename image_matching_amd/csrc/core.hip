@@ -69,6 +69,81 @@ void imatch_stage_download_end(imatch_ctx* ctx, uint8_t* out, size_t bytes) {
     memcpy(out, (const uint8_t*)ctx->is + is_half(ctx), bytes);
 }
 
+// ---- host worker pool ------------------------------------------------------------------------------
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+struct imatch_workers {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)>* fn = nullptr;
+    int n = 0;                 // items of the current job
+    std::atomic<int> next{0};  // next item to take
+    int running = 0;           // workers that have not finished the current job
+    unsigned long job = 0;     // job counter: a worker runs each job once
+    bool stop = false;
+};
+
+static void worker_main(imatch_workers* w) {
+    unsigned long seen = 0;
+    for (;;) {
+        std::unique_lock<std::mutex> lk(w->m);
+        w->cv_work.wait(lk, [&] { return w->stop || w->job != seen; });
+        if (w->stop) return;
+        seen = w->job;
+        const std::function<void(int)>* fn = w->fn;
+        const int n = w->n;
+        lk.unlock();
+        for (int i = w->next.fetch_add(1); i < n; i = w->next.fetch_add(1)) (*fn)(i);
+        lk.lock();
+        if (--w->running == 0) w->cv_done.notify_one();
+    }
+}
+
+void imatch_parallel_for(imatch_ctx* ctx, int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (n == 1 || !ctx) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    if (!ctx->workers) {
+        ctx->workers = new imatch_workers();
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nt = (int)std::min<unsigned>(16u, hw ? hw : 4u) - 1;   // the caller works too
+        for (int t = 0; t < nt; ++t) ctx->workers->threads.emplace_back(worker_main, ctx->workers);
+    }
+    imatch_workers* w = ctx->workers;
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        w->fn = &fn;
+        w->n = n;
+        w->next.store(0);
+        w->running = (int)w->threads.size();
+        ++w->job;
+    }
+    w->cv_work.notify_all();
+    for (int i = w->next.fetch_add(1); i < n; i = w->next.fetch_add(1)) fn(i);
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv_done.wait(lk, [&] { return w->running == 0; });
+    w->fn = nullptr;
+}
+
+void imatch_workers_destroy(imatch_ctx* ctx) {
+    if (!ctx || !ctx->workers) return;
+    {
+        std::lock_guard<std::mutex> lk(ctx->workers->m);
+        ctx->workers->stop = true;
+    }
+    ctx->workers->cv_work.notify_all();
+    for (auto& t : ctx->workers->threads) t.join();
+    delete ctx->workers;
+    ctx->workers = nullptr;
+}
+
 int imatch_hs_reserve(imatch_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->hs_bytes) return IMATCH_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -184,6 +259,7 @@ void imatch_destroy(imatch_ctx* ctx) {
     imatch_sift_state_free(ctx);
     imatch_pool_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    imatch_workers_destroy(ctx);
     if (ctx->hs) (void)hipHostFree(ctx->hs);
     if (ctx->is) (void)hipHostFree(ctx->is);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

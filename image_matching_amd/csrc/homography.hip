@@ -276,12 +276,8 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
             }
         found[b] = 1;
     };
-    if (nseg >= 4) {  // the problems are independent: refit them on host threads (at most 16)
-        const int nt = std::min(nseg, 16);
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nt; ++t)
-            pool.emplace_back([&, t]() { for (int b = t; b < nseg; b += nt) finish(b); });
-        for (auto& th : pool) th.join();
+    if (nseg >= 4) {  // the problems are independent: refit them on the context's host workers
+        imatch_parallel_for(ctx, nseg, [&](int b) { finish(b); });
     } else {
         for (int b = 0; b < nseg; ++b) finish(b);
     }

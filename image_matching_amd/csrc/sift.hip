@@ -1457,15 +1457,11 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             memcpy(rec, kps.data(), (size_t)K * sizeof(KpRec));
             K_of[b] = K;
         };
-        if (batch >= 4) {  // the images' lists are independent: sort them on as many host threads (at most 16)
-            const int nt = std::min(batch, 16);
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nt; ++t)
-                pool.emplace_back([&, t]() {
-                    std::vector<KpRec> kps;
-                    for (int b = t; b < batch; b += nt) finish_image(b, kps);
-                });
-            for (auto& th : pool) th.join();
+        if (batch >= 4) {  // the images' lists are independent: sort them on the context's host workers
+            imatch_parallel_for(ctx, batch, [&](int b) {
+                std::vector<KpRec> kps;
+                finish_image(b, kps);
+            });
         } else {
             std::vector<KpRec> kps;
             for (int b = 0; b < batch; ++b) finish_image(b, kps);
