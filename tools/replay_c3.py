@@ -50,7 +50,11 @@ def run(frames):
 
 
 run(flight[:12])                 # warm-up: arenas, pools
+import gc
+gc.collect()
+gc.disable()                     # a generational collection (~35 ms here) inside the loop would read as frame time
 pf, wall = run(flight)
+gc.enable()
 truth = {tr["stamp"]: tr for _, tr in flight}
 err = [np.hypot(f["x_m"] - truth[f["stamp"]]["cx"] * map_px, f["y_m"] - truth[f["stamp"]]["cy"] * map_px) for f in pf.fixes]
 if os.environ.get("REPLAY_PROFILE"):
