@@ -22,8 +22,10 @@ max over ranks between two barriers). What happens to the map depends on its siz
               all-gathered, every rank matches all batches against its shard, and an all_to_all returns the
               per-shard top-2 to the batch's owner (image_matching_amd/sharded.py: the layout of configs[3]/[4],
               maps of 5M-20M descriptors).
-In replicated mode a short sharded loop is run AFTER the timed region and reported beside the headline as
-"sharded_map" (its failure is reported there and does not touch `value`).
+In replicated mode a short sharded loop is run AFTER the headline is final and reported beside it as "sharded_map":
+one batch compared bit for bit with the whole-map result, then 10 timed steps. It runs under a watchdog
+(IMATCH_BENCH_EXTRA_TIMEOUT seconds, default 240): a failure or a stuck collective there is reported in that
+field and cannot change or withhold `value`. IMATCH_BENCH_SHARDED_EXTRA=0 skips it.
 
 One JSON line on stdout (rank 0). Progress goes to stderr."""
 import argparse
@@ -292,9 +294,8 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
 
-    # N > 1, replicated map: the sharded-map exchange path, outside the timed region
-    sharded_extra = None
-    if world > 1 and map_mode == "replicated" and B > 1:
+    # N > 1, replicated map: the sharded-map exchange path, run AFTER the headline is final (see the watchdog below)
+    def sharded_map_extra():
         try:
             mt_sh = sharded.ShardedMatcher(ctx, f_shard, lo, dev)
             n_sh = 10
@@ -317,13 +318,13 @@ def main():
             barrier()
             tw = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            sharded_extra = {"frames_per_s": world * B * n_sh / float(tw.item()), "ms_per_step": float(tw.item()) / n_sh * 1e3,
-                             "steps": n_sh, "knn_launch_ms": ctx.knn2_kernel_ms(),
-                             "per_launch": "%d query rows (all ranks' batches, padded) x %d shard rows" % (world * bq_cap, hi - lo),
-                             "exchange": "all_gather of u8 query rows + all_to_all of per-shard top-2 (RCCL), merge_top2",
-                             "identical_to_whole_map": bool(same.item())}
+            return {"frames_per_s": world * B * n_sh / float(tw.item()), "ms_per_step": float(tw.item()) / n_sh * 1e3,
+                    "steps": n_sh, "knn_launch_ms": ctx.knn2_kernel_ms(),
+                    "per_launch": "%d query rows (all ranks' batches, padded) x %d shard rows" % (world * bq_cap, hi - lo),
+                    "exchange": "all_gather of u8 query rows + all_to_all of per-shard top-2 (RCCL), merge_top2",
+                    "identical_to_whole_map": bool(same.item())}
         except Exception as e:    # must not take the headline down with it
-            sharded_extra = {"error": repr(e)[:300]}
+            return {"error": repr(e)[:300]}
 
     # single-frame latency, outside the timed region: the per-frame calls, one frame at a time
     single_ms = None
@@ -387,8 +388,6 @@ def main():
                 out["roofline"]["traffic_note"] = "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE, " + pmc["source"]
         except (OSError, ValueError, KeyError):
             pass
-        if sharded_extra is not None:
-            out["sharded_map"] = sharded_extra
         if single_ms is not None:
             out["single_frame"] = {"ms_per_frame": single_ms, "frames_per_s": 1e3 / single_ms,
                                    "note": "one frame at a time through the single-frame entry points, measured after "
@@ -400,7 +399,36 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames_h[0], d_s, n_map, map_xy[:n_s], ratio, threads)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
+
+    # The headline is final here. At N > 1 with a replicated map the sharded-map loop runs now, under a watchdog: this
+    # is the only part of the run that depends on the all_gather / all_to_all exchange, and if it does not come back
+    # (every rank would then sit in the same collective) each rank's watchdog ends its process with status 0 after rank 0
+    # has printed the line without it.
+    printed = threading.Lock()
+
+    def emit(extra):
+        with printed:
+            if rank == 0 and out is not None and "_done" not in out:
+                if extra is not None:
+                    out["sharded_map"] = extra
+                out["_done"] = True
+                print(json.dumps({k: v for k, v in out.items() if k != "_done"}), flush=True)
+
+    if world > 1 and map_mode == "replicated" and B > 1 and os.environ.get("IMATCH_BENCH_SHARDED_EXTRA", "1") != "0":
+        finished = threading.Event()
+
+        def watchdog():
+            if not finished.wait(float(os.environ.get("IMATCH_BENCH_EXTRA_TIMEOUT", "240"))):
+                emit({"error": "the sharded-map loop did not finish in time; the headline does not depend on it"})
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        extra = sharded_map_extra()
+        finished.set()
+        emit(extra)
+    else:
+        emit(None)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
