@@ -297,6 +297,181 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
     }
 }
 
+// ---- the same kernel on v_mfma_f32_16x16x32_bf16 ---------------------------------------------------
+// Same operand roles (train rows = A, queries = B), same LDS image and stage loader, same bound exchange. A lane owns
+// query (lane & 15) of a 16-query block and sees rows 4*(lane >> 4) .. +3 of a 16-row tile, so a query's running top-2 is
+// kept by four lanes (four partial lists per train chunk) -- in REGISTERS here: with 4 accumulator registers per block
+// instead of 16 there is room for them, and the insertion path touches no LDS. Per MI355X_MICROARCH.md a 16x16x32 loop
+// delivers about 1.15x the FLOP/s of a 32x32x16 loop at equal cycles per FLOP (it draws less power; this kernel ran at
+// 2.09 GHz by GRBM_GUI_ACTIVE), which is the reason for this variant.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int QB, int TN, int XM>   // QB blocks of 16 queries per wave (8: 128 queries, 512 per workgroup as above)
+__global__ void __launch_bounds__(256, 2)
+knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ thneg,
+              int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi,
+              int* __restrict__ gthr) {
+    static_assert(QB % 4 == 0, "thresholds are fetched 64 queries at a time");
+    constexpr int STAGE_U4 = TN * 16 + TN / 4;
+    constexpr int NT = TN / 16;                  // 16-row tiles per stage
+    constexpr int TH_F = 3 * (QB / 4) * 64;      // fetched thresholds per wave: [3][QB/4][64 queries]
+    __shared__ uint4 lds[2 * STAGE_U4 + (4 * TH_F) / 4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4, grp = q >> 1;
+    float* const thl = (float*)(lds + 2 * STAGE_U4) + wave * TH_F;
+
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int chunk = (j / nQt) * 8 + xcd;
+    const int qt = j % nQt;
+    if (chunk >= nChunks) return;
+    const int s_begin = (int)((int64_t)nStages * chunk / nChunks);
+    const int s_end = (int)((int64_t)nStages * (chunk + 1) / nChunks);
+
+    // resident query fragments: lane holds q[row r of block qb][k = 32 t + 8 q .. +7] = 16-byte chunk 4 t + q
+    const int64_t qrow0 = (int64_t)qt * (4 * 16 * QB) + wave * (16 * QB);
+    bf16x8 qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint4 u = Qd[(qrow0 + qb * 16 + r) * 16 + 4 * t + q];
+            qf[qb][t] = __builtin_bit_cast(bf16x8, u);
+        }
+
+    const int* gq = gthr + qrow0;                 // wave-uniform base of this wave's thresholds
+    float G[QB], b1[QB], b2[QB];
+    int i1[QB], i2[QB];
+    // fetched thresholds of block qb, word a: thl[(a * (QB/4) + (qb >> 2)) * 64 + (qb & 3) * 16 + r]
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        b1[qb] = FLT_MAX; b2[qb] = FLT_MAX; i1[qb] = -1; i2[qb] = -1;
+        const int t0 = __hip_atomic_load(gq + qb * 16 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int at = (qb >> 2) * 64 + (qb & 3) * 16 + r;
+        thl[at] = __int_as_float(t0);
+        thl[(QB / 4) * 64 + at] = __int_as_float(0x7f7f7f7f);
+        thl[2 * (QB / 4) * 64 + at] = __int_as_float(0x7f7f7f7f);
+        G[qb] = -0.5f * ord_f(t0);
+    }
+
+    const unsigned lds0 = lds_addr_of(lds);
+    auto stage = [&](int s, int buf) {
+        const unsigned ln = lane_now();
+        const unsigned r0 = (unsigned)wave * 4u + (ln >> 4);
+        const unsigned lane_off = (r0 * 16 + ((ln & 15) ^ (r0 & 15))) * 16;   // bytes
+        const char* src = (const char*)(Td + (int64_t)s * TN * 16);
+#pragma unroll
+        for (int i = 0; i < (TN * 16) / 256; ++i)
+            glds16(uniform_ptr(src + i * 4096), lane_off, lds0 + (buf * STAGE_U4 + i * 256 + wave * 64) * 16);
+        if (wave < TN / 64)
+            glds4(uniform_ptr(thneg + (int64_t)s * TN + wave * 64), ln * 4,
+                  lds0 + (buf * STAGE_U4 + TN * 16) * 16 + wave * 256);
+    };
+
+    if (s_begin < s_end) stage(s_begin, 0);
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int age = s - s_begin;
+        const bool exchange = age < 8 || (age & XM) == 0;   // XM + 1 stages between bound exchanges
+        if (exchange) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const int at = (qb >> 2) * 64 + (qb & 3) * 16 + r;
+                const float tg = ord_f(__float_as_int(thl[at]));
+                const float ta = ord_f(__float_as_int(thl[(QB / 4) * 64 + at]));
+                const float tb = ord_f(__float_as_int(thl[2 * (QB / 4) * 64 + at]));
+                // rows of lists q = 0,1 and of lists q = 2,3 are disjoint: the larger of the two groups' least bests
+                // bounds the second-best, as does the least second-best of any list
+                G[qb] = fmaxf(G[qb], -0.5f * fminf(tg, fmaxf(ta, tb)));
+                if (b2[qb] < tg) atomicMin(const_cast<int*>(gq) + qb * 16 + r, ord_i(b2[qb]));
+                if (b1[qb] < (grp ? tb : ta)) atomicMin(const_cast<int*>(gq) + (1 + grp) * Qpad + qb * 16 + r, ord_i(b1[qb]));
+            }
+        }
+        if (s + 1 < s_end) stage(s + 1, buf ^ 1);
+        if (exchange) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int jj = 0; jj < QB / 4; ++jj)
+                    glds4_sc1(uniform_ptr(gq + a * Qpad + jj * 64), lane_now() * 4,
+                              lds_addr_of(thl) + (a * (QB / 4) + jj) * 256);
+        }
+        const unsigned lf = lane_now();
+        const unsigned frag_off = (lf & 15) * 256u + ((((lf >> 4) ^ lf) & 15) << 4);
+        const uint4* img = lds + buf * STAGE_U4;
+        bf16x8 af[4];
+        f32x4 hneg;
+        // chunk (4t + q) ^ (r & 15) = ((q ^ r) & 15) ^ 4t: one per-lane address XOR an immediate per k-step
+        auto load_tile = [&](int tile) {
+            const unsigned a0 = (unsigned)tile * 4096u + frag_off;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint4 u = *(const uint4*)((const char*)img + (a0 ^ (unsigned)(t << 6)));
+                af[t] = __builtin_bit_cast(bf16x8, u);
+            }
+            const uint4 u = img[TN * 16 + tile * 4 + (int)(lf >> 4)];   // -|t|^2/2 of rows 4q .. 4q+3 of the tile
+            hneg[0] = __uint_as_float(u.x); hneg[1] = __uint_as_float(u.y);
+            hneg[2] = __uint_as_float(u.z); hneg[3] = __uint_as_float(u.w);
+        };
+        auto chain = [&](int qb) {
+            f32x4 acc = hneg;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], qf[qb][t], acc, 0, 0, 0);
+            return acc;
+        };
+        auto epilogue = [&](const f32x4& a, int qb, int tile) {
+            const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+            if (__builtin_amdgcn_ballot_w64(m >= G[qb])) {
+                int rowbase = s * TN + tile * 16 + 4 * q;
+                asm volatile("" : "+v"(rowbase));
+                const float g = G[qb];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {   // ascending train index, strict <: the lowest index wins ties
+                    const float v = a[reg];
+                    const bool pass = v >= g;
+                    if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
+                    const float x = -2.0f * v;
+                    const int idx = rowbase + reg;
+                    const bool lt1 = pass && x < b1[qb];
+                    const bool lt2 = pass && !lt1 && x < b2[qb];
+                    b2[qb] = lt1 ? b1[qb] : (lt2 ? x : b2[qb]);
+                    i2[qb] = lt1 ? i1[qb] : (lt2 ? idx : i2[qb]);
+                    b1[qb] = lt1 ? x : b1[qb];
+                    i1[qb] = lt1 ? idx : i1[qb];
+                }
+                G[qb] = fmaxf(g, -0.5f * b2[qb]);
+            }
+        };
+
+        load_tile(0);
+        f32x4 acc0 = chain(0), acc1;
+#pragma unroll 1
+        for (int tile = 0; tile < NT; ++tile) {
+#pragma unroll
+            for (int qb = 0; qb < QB; qb += 2) {
+                acc1 = chain(qb + 1);
+                if (qb == QB - 2 && tile + 1 < NT) load_tile(tile + 1);
+                epilogue(acc0, qb, tile);
+                if (qb + 2 < QB) acc0 = chain(qb + 2);
+                else if (tile + 1 < NT) acc0 = chain(0);
+                epilogue(acc1, qb + 1, tile);
+            }
+        }
+    }
+
+    // one partial list per (chunk, row quarter)
+    const int64_t list = (int64_t)chunk * 4 + q;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int64_t o = list * Qpad + qrow0 + qb * 16 + r;
+        pb[o] = make_float2(b1[qb], b2[qb]);
+        pi[o] = make_int2(i1[qb], i2[qb]);
+    }
+}
+
 __device__ inline void top2_insert(int& s1, int& j1, int& s2, int& j2, int s, int j) {
     if (s < s1 || (s == s1 && j < j1)) {
         s2 = s1; j2 = j1; s1 = s; j1 = j;
@@ -548,7 +723,13 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     int QB = 4;
     if (q->n <= 128) QB = 1;
     else if (q->n <= 512) QB = 2;
-    const int TNs = 64;
+    // QB == 4 (the large-Q case) runs on the 16x16x32 MFMA with 128-row stages (IMATCH_KNN_MFMA16=0: the 32x32x16
+    // kernel, IMATCH_KNN_TN=64: 64-row stages -- both kept for A/B measurements, profiles/r1_knn_shapes.txt)
+    static const int mfma16 = getenv("IMATCH_KNN_MFMA16") ? atoi(getenv("IMATCH_KNN_MFMA16")) : 1;
+    static const int tn_env = getenv("IMATCH_KNN_TN") ? atoi(getenv("IMATCH_KNN_TN")) : 128;
+    static const int xmask = getenv("IMATCH_KNN_XMASK") ? atoi(getenv("IMATCH_KNN_XMASK")) : 7;
+    const bool use16 = mfma16 && QB == 4;
+    const int TNs = (use16 && tn_env == 128 && t->n_pad % 128 == 0) ? 128 : 64;
     const int qtile = 4 * 32 * QB;
     const int64_t Qpad = q->n_pad;  // multiple of 1024, so of every qtile
     const int nQt = (int)((q->n + qtile - 1) / qtile);
@@ -564,7 +745,7 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     if (nChunks > nStages / 4) nChunks = (nStages / 4 / 8) * 8;
     if (nChunks < 8) nChunks = 8;
     if (const char* e = getenv("IMATCH_KNN_CHUNKS")) nChunks = std::max(8, atoi(e) / 8 * 8);  // tuning override
-    const int64_t nLists = (int64_t)nChunks * 2;
+    const int64_t nLists = (int64_t)nChunks * (use16 ? 4 : 2);
     const size_t pbytes = (size_t)nLists * Qpad * 8;
     const size_t gbytes = ((size_t)Qpad * 12 + 255) & ~(size_t)255;   // three bounds per query
     int rc = imatch_ws_reserve(ctx, 2 * pbytes + gbytes);
@@ -574,7 +755,15 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     int* gthr = (int*)((char*)ctx->ws + 2 * pbytes);
     HIP_TRY(ctx, hipMemsetAsync(gthr, 0x7f, gbytes, ctx->stream));  // 0x7f7f7f7f = 3.39e38 as a float
     if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (QB == 4) launch_knn<4, 64>(ctx, q, t, nQt, nChunks, Qpad, pb, pi, gthr);
+    if (use16) {
+        const unsigned grid = (unsigned)(nQt * nChunks);
+#define LAUNCH16(TN_, XM_) hipLaunchKernelGGL((knn2_kernel16<8, TN_, XM_>), dim3(grid), dim3(256), 0, ctx->stream, \
+        (const uint4*)q->desc, (const uint4*)t->desc, t->hneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr)
+        if (TNs == 128 && xmask == 3) LAUNCH16(128, 3);
+        else if (TNs == 128) LAUNCH16(128, 7);
+        else LAUNCH16(64, 3);
+#undef LAUNCH16
+    } else if (QB == 4) launch_knn<4, 64>(ctx, q, t, nQt, nChunks, Qpad, pb, pi, gthr);
     else if (QB == 2) launch_knn<2, 64>(ctx, q, t, nQt, nChunks, Qpad, pb, pi, gthr);
     else launch_knn<1, 64>(ctx, q, t, nQt, nChunks, Qpad, pb, pi, gthr);
     HIP_TRY(ctx, hipGetLastError());
