@@ -367,7 +367,8 @@ def main():
                                       ("map sharded x%d, frames data-parallel" % world if exchange else
                                        "map replicated on %d GPUs, frames data-parallel, no collective" % world)},
             "knn_gdist_per_s": world * q_per_launch * float(n_local) / (knn_ms * 1e-3) / 1e9,
-            "roofline": {"kernel": "knn2_kernel (bf16 MFMA, fused top-2)", "bound": "mfma", "achieved": achieved_tf,
+            "roofline": {"kernel": ("knn2_kernel16<8,128> (bf16 MFMA 16x16x32, fused top-2)" if q_per_launch > 512
+                                    else "knn2_kernel (bf16 MFMA 32x32x16, fused top-2)"), "bound": "mfma", "achieved": achieved_tf,
                          "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_BF16_PEAK_TF,
                          "traffic": None, "launch_ms": knn_ms,
                          "per_launch": "%d queries x %d train rows x 256 flop" % (int(q_per_launch), n_local)},

@@ -33,6 +33,8 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -- python3 "$
     > "$out/pmc_write.json" 2> "$out/pmc_write.err" || exit 1
 python3 "$root/tools/pmc_sum.py" "$out"/pmc_write/*/*_results.db "$out/pmc_write.md" > /dev/null || exit 1
 
+python3 "$root/tools/pmc_merge.py" "$out/pmc_fetch.md" "$out/pmc_write.md" "$out/bench.json" "$out/pmc.md" "$out/pmc_knn.json" || exit 1
+
 step replay
 timeout -k 10 400 python3 "$root/tools/replay_c3.py" 240 8192 > "$out/replay_c3.json" 2> "$out/replay_c3.err" || exit 1
 
