@@ -13,6 +13,7 @@ _lib = None
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_f32p = ctypes.POINTER(ctypes.c_float)
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_f64p = ctypes.POINTER(ctypes.c_double)
 c_i64 = ctypes.c_int64
 c_vp = ctypes.c_void_p
 
@@ -55,6 +56,12 @@ SIGNATURES = {
                                     ctypes.c_int, ctypes.c_int, c_u8p]),
     "imatch_resize_area": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_u8p,
                                           ctypes.c_int, ctypes.c_int]),
+    "imatch_cvt_gray": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_u8p]),
+    "imatch_fisheye_new_camera_matrix": (ctypes.c_int, [c_f64p, c_f64p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                        c_f64p]),
+    "imatch_fisheye_undistort": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                c_f64p, c_f64p, c_f64p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, c_u8p]),
     "imatch_sift_extract": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(SiftParams), ctypes.POINTER(c_vp)]),
     "imatch_sift_extract_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -278,6 +285,48 @@ class Context:
         with self.lock:
             self._check(self.lib.imatch_resize_area(self._h, _ptr(img, c_u8p), img.shape[0], img.shape[1],
                                                     img.strides[0], _ptr(out, c_u8p), dh, dw))
+        return out
+
+    # -- camera pre-step --------------------------------------------------------------------
+    @staticmethod
+    def _color(img):
+        img = np.asarray(img)
+        if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
+            raise ValueError("expected a [h, w, 3] uint8 image, got %s %s" % (img.dtype, img.shape))
+        if img.strides[2] != 1 or img.strides[1] != 3 or img.strides[0] < 3 * img.shape[1]:
+            img = np.ascontiguousarray(img)
+        return img
+
+    def cvt_gray(self, img, rgb=False):
+        """cv2.cvtColor(img, COLOR_BGR2GRAY) (rgb=True: COLOR_RGB2GRAY)."""
+        img = self._color(img)
+        out = np.empty(img.shape[:2], np.uint8)
+        with self.lock:
+            self._check(self.lib.imatch_cvt_gray(self._h, _ptr(img, c_u8p), img.shape[0], img.shape[1], img.strides[0],
+                                                 1 if rgb else 0, _ptr(out, c_u8p)))
+        return out
+
+    def fisheye_undistort(self, img, K, D, new_K, window=None, to_gray=False):
+        """initUndistortRectifyMap(K, D, I, new_K, size, CV_16SC2) + remap(INTER_AREA, BORDER_CONSTANT), restricted to
+        window = (x0, y0, width, height) of the rectified image (default: all of it)."""
+        img = np.asarray(img)
+        if img.ndim == 2:
+            img = self._gray(img)
+            ch = 1
+        else:
+            img = self._color(img)
+            ch = 3
+        h, w = img.shape[:2]
+        x0, y0, cw, chh = window if window is not None else (0, 0, w, h)
+        K = np.ascontiguousarray(K, np.float64).reshape(9)
+        D = np.ascontiguousarray(D, np.float64).reshape(4)
+        new_K = np.ascontiguousarray(new_K, np.float64).reshape(9)
+        out = np.empty((chh, cw) if (to_gray or ch == 1) else (chh, cw, 3), np.uint8)
+        with self.lock:
+            self._check(self.lib.imatch_fisheye_undistort(self._h, _ptr(img, c_u8p), h, w, ch, img.strides[0],
+                                                          _ptr(K, c_f64p), _ptr(D, c_f64p), _ptr(new_K, c_f64p), int(x0),
+                                                          int(y0), int(cw), int(chh), 1 if to_gray else 0,
+                                                          _ptr(out, c_u8p)))
         return out
 
     def sift_extract(self, img, params=None):

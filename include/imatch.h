@@ -79,6 +79,24 @@ int imatch_clahe(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, 
 int imatch_resize_area(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride,
                        uint8_t* out, int dh, int dw);
 
+/* Camera pre-step ---------------------------------------- */
+/* Replaces cv2.cvtColor(image, cv2.COLOR_BGR2GRAY) (position_finder.py:171, mezhcadr.py:85,
+ * photo_publisher.py:112) and, with swap_rb = 1, COLOR_RGB2GRAY (image_processing.py:54). img is 8-bit with 3
+ * interleaved channels, `stride` bytes per row; out is [h][w]. */
+int imatch_cvt_gray(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, int swap_rb, uint8_t* out);
+/* Replaces cv2.fisheye.estimateNewCameraMatrixForUndistortRectify(K, D, (w, h), np.eye(3), balance=balance)
+ * (csi_camera.py:159, photo_publisher.py:164). K, newK: row-major 3x3; D: k1..k4. Host arithmetic only. */
+int imatch_fisheye_new_camera_matrix(const double* K, const double* D, int w, int h, double balance, double* newK);
+/* Replaces the rest of csi_camera.undistort (csi_camera.py:160-166; photo_publisher.py:165-171):
+ * cv2.fisheye.initUndistortRectifyMap(K, D, eye(3), newK, (w, h), CV_16SC2) -> cv2.remap(img, map1, map2,
+ * INTER_AREA (= linear inside remap), BORDER_CONSTANT) -> the slice [y0:y0+ch, x0:x0+cw] of the result. The maps are
+ * built once per calibration and window and stay in HBM (the reference rebuilds them every frame); only the kept
+ * window is computed. channels = 1 or 3 (interleaved); to_gray = 1 (3-channel input) returns
+ * cvtColor(BGR2GRAY) of the slice, [ch][cw], the form position_finder consumes; else out is [ch][cw][channels]. */
+int imatch_fisheye_undistort(imatch_ctx* ctx, const uint8_t* img, int h, int w, int channels, int stride, const double* K,
+                             const double* D, const double* newK, int x0, int y0, int cw, int ch, int to_gray,
+                             uint8_t* out);
+
 /* SIFT extraction ---------------------------------------------------------- */
 typedef struct imatch_sift_params {
     int n_octave_layers;       /* nOctaveLayers_sift   (MF:31), OpenCV default 3 */

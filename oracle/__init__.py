@@ -218,3 +218,84 @@ def homography(src, dst, thr=0.1, seed=0):
     if not ok:
         return None, None
     return H, mask[:n]
+
+
+# ---- camera pre-step (camera_oracle.c) ---------------------------------------------------------
+_f64p = ctypes.POINTER(ctypes.c_double)
+_i16p = ctypes.POINTER(ctypes.c_int16)
+_u16p = ctypes.POINTER(ctypes.c_uint16)
+
+
+def _declare_camera(L):
+    c_int = ctypes.c_int
+    L.oracle_cvt_gray.argtypes = [_u8p, c_int, c_int, c_int, _u8p]
+    L.oracle_cvt_gray.restype = None
+    L.oracle_fisheye_new_K.argtypes = [_f64p, _f64p, c_int, c_int, ctypes.c_double, _f64p]
+    L.oracle_fisheye_new_K.restype = None
+    L.oracle_fisheye_maps.argtypes = [_f64p, _f64p, _f64p, c_int, c_int, _i16p, _u16p]
+    L.oracle_fisheye_maps.restype = None
+    L.oracle_remap_linear.argtypes = [_u8p, c_int, c_int, c_int, _i16p, _u16p, c_int, c_int, _u8p]
+    L.oracle_remap_linear.restype = None
+
+
+_declare_before_camera = _declare
+
+
+def _declare(L):  # noqa: F811
+    _declare_before_camera(L)
+    _declare_camera(L)
+
+
+def cvt_gray(img, rgb=False):
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) (rgb: COLOR_RGB2GRAY)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty(img.shape[:2], np.uint8)
+    lib().oracle_cvt_gray(_p(img, _u8p), img.shape[0], img.shape[1], 1 if rgb else 0, _p(out, _u8p))
+    return out
+
+
+def fisheye_new_K(K, D, size, balance=0.0):
+    """cv2.fisheye.estimateNewCameraMatrixForUndistortRectify(K, D, size, eye(3), balance=balance)."""
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    D = np.ascontiguousarray(D, np.float64).reshape(4)
+    out = np.empty(9, np.float64)
+    lib().oracle_fisheye_new_K(_p(K, _f64p), _p(D, _f64p), int(size[0]), int(size[1]), float(balance), _p(out, _f64p))
+    return out.reshape(3, 3)
+
+
+def fisheye_maps(K, D, new_K, size):
+    """cv2.fisheye.initUndistortRectifyMap(K, D, eye(3), new_K, size, CV_16SC2) -> (map1 i16 [h,w,2], map2 u16 [h,w])."""
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    D = np.ascontiguousarray(D, np.float64).reshape(4)
+    new_K = np.ascontiguousarray(new_K, np.float64).reshape(9)
+    w, h = int(size[0]), int(size[1])
+    m1 = np.empty((h, w, 2), np.int16)
+    m2 = np.empty((h, w), np.uint16)
+    lib().oracle_fisheye_maps(_p(K, _f64p), _p(D, _f64p), _p(new_K, _f64p), w, h, _p(m1, _i16p), _p(m2, _u16p))
+    return m1, m2
+
+
+def remap_linear(img, map1, map2):
+    """cv2.remap(img, map1, map2, INTER_AREA (linear inside remap), BORDER_CONSTANT)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    map1 = np.ascontiguousarray(map1, np.int16)
+    map2 = np.ascontiguousarray(map2, np.uint16)
+    dh, dw = map2.shape
+    out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, ch), np.uint8)
+    lib().oracle_remap_linear(_p(img, _u8p), img.shape[0], img.shape[1], ch, _p(map1, _i16p), _p(map2, _u16p), dh, dw,
+                              _p(out, _u8p))
+    return out
+
+
+def undistort(img, K, D, DIM, balance=0.0, scale=0.5):
+    """csi_camera.undistort (csi_camera.py:138-167) with dim2 = dim3 = the input size."""
+    dim1 = img.shape[:2][::-1]
+    scaled_K = np.array(K, np.float64) * dim1[0] / DIM[0]
+    scaled_K[2][2] = 1.0
+    new_K = fisheye_new_K(scaled_K, D, dim1, balance)
+    m1, m2 = fisheye_maps(scaled_K, D, new_K, dim1)
+    und = remap_linear(img, m1, m2)
+    s0, s1 = int((dim1[0] * (1 - scale)) / 2), int((dim1[1] * (1 - scale)) / 2)
+    t0, t1 = int(dim1[0] * scale), int(dim1[1] * scale)
+    return und[s1:s1 + t1, s0:s0 + t0]
