@@ -62,6 +62,8 @@ SIGNATURES = {
     "imatch_fisheye_undistort": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 c_f64p, c_f64p, c_f64p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, c_u8p]),
+    "imatch_draw_matches": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int, c_u8p]),
     "imatch_sift_extract": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(SiftParams), ctypes.POINTER(c_vp)]),
     "imatch_sift_extract_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -327,6 +329,22 @@ class Context:
                                                           _ptr(K, c_f64p), _ptr(D, c_f64p), _ptr(new_K, c_f64p), int(x0),
                                                           int(y0), int(cw), int(chh), 1 if to_gray else 0,
                                                           _ptr(out, c_u8p)))
+        return out
+
+    def draw_matches(self, img1, xy1, img2, xy2):
+        """The canvas of cv2.drawMatchesKnn(img1, kp1, img2, kp2, good, None, NOT_DRAW_SINGLE_POINTS): xy1[i] <-> xy2[i]
+        are the good matches' keypoint positions."""
+        img1, img2 = self._gray(img1), self._gray(img2)
+        xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
+        xy2 = np.ascontiguousarray(xy2, np.float32).reshape(-1, 2)
+        if len(xy1) != len(xy2):
+            raise ValueError("one point of each image per match")
+        out = np.empty((max(img1.shape[0], img2.shape[0]), img1.shape[1] + img2.shape[1], 3), np.uint8)
+        with self.lock:
+            self._check(self.lib.imatch_draw_matches(self._h, _ptr(img1, c_u8p), img1.shape[0], img1.shape[1],
+                                                     img1.strides[0], _ptr(img2, c_u8p), img2.shape[0], img2.shape[1],
+                                                     img2.strides[0], _ptr(xy1, c_f32p), _ptr(xy2, c_f32p), len(xy1),
+                                                     _ptr(out, c_u8p)))
         return out
 
     def sift_extract(self, img, params=None):

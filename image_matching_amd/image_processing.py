@@ -36,10 +36,11 @@ class image_processing():
                 path = os.path.join(data_path, filename + ".TIF")
             from PIL import Image
             Image.MAX_IMAGE_PIXELS = None
-            rgb = np.asarray(Image.open(path).convert("RGB"), dtype=np.int32)
-            # the reference applies COLOR_RGB2GRAY to imread's BGR data (image_processing.py:42,54):
-            # OpenCV's fixed-point weights land on the swapped channels
-            self.img = ((rgb[..., 2] * 4899 + rgb[..., 1] * 9617 + rgb[..., 0] * 1868 + 8192) >> 14).astype(np.uint8)
+            bgr = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)[..., ::-1])  # imread order
+            # the reference applies COLOR_RGB2GRAY to imread's BGR data (image_processing.py:42,54): OpenCV's
+            # weights land on the swapped channels; same kernel as the frames' BGR2GRAY (imatch_cvt_gray)
+            from .utils import default_context
+            self.img = default_context().cvt_gray(bgr, rgb=True)
             with open(os.path.join(data_path, filename + ".@@@")) as f:
                 for line in f.readlines()[2:]:
                     vals = [float(t) for t in line.split()]

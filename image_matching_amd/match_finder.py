@@ -177,9 +177,14 @@ class match_finder():
         good = GoodMatches(q, idx[q, 0], dist[q, 0])     # [[DMatch], ...] when read; see cvtypes.GoodMatches
         img3 = None
         if self.draw_matches:
-            img3 = draw.matches_canvas(cadr.img, cadr.kp.xy if hasattr(cadr.kp, "xy") else _xy(cadr.kp),
-                                       roi.img, roi.kp.xy if hasattr(roi.kp, "xy") else _xy(roi.kp),
-                                       list(zip(good.query_idx.tolist(), good.train_idx.tolist())))
+            xy1 = cadr.kp.xy if hasattr(cadr.kp, "xy") else _xy(cadr.kp)
+            xy2 = roi.kp.xy if hasattr(roi.kp, "xy") else _xy(roi.kp)
+            if np.ndim(cadr.img) == 2 and np.ndim(roi.img) == 2:      # composed and drawn on the GPU
+                img3 = self.ctx.draw_matches(cadr.img, np.asarray(xy1)[good.query_idx], roi.img,
+                                             np.asarray(xy2)[good.train_idx])
+            else:
+                img3 = draw.matches_canvas(cadr.img, xy1, roi.img, xy2,
+                                           list(zip(good.query_idx.tolist(), good.train_idx.tolist())))
         return good, img3
 
     def find_keypoints_transform(self, matches, roi, cadr, img_for_pub):

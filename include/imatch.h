@@ -97,6 +97,15 @@ int imatch_fisheye_undistort(imatch_ctx* ctx, const uint8_t* img, int h, int w, 
                              const double* D, const double* newK, int x0, int y0, int cw, int ch, int to_gray,
                              uint8_t* out);
 
+/* Replaces cv2.drawMatchesKnn(cadr.img, keypoints_1, roi.img, roi.kp, good, None,
+ * flags=cv2.DrawMatchesFlags_NOT_DRAW_SINGLE_POINTS) (MF:196): out is the [max(h1,h2)][w1+w2][3] canvas, img1 left,
+ * img2 right (8-bit gray, replicated to three channels), and for each of the n good matches xy1[i] <-> xy2[i]
+ * (f32 [n][2], the matched keypoints' .pt) a circle around both points joined by a line. Composed and drawn on the
+ * GPU. Layout and dtype are cv2's; the pixels of the primitives follow "Spec D" (oracle/draw_oracle.c), since cv2's
+ * anti-aliased drawing in RNG colours cannot be reproduced by any caller. */
+int imatch_draw_matches(imatch_ctx* ctx, const uint8_t* img1, int h1, int w1, int stride1, const uint8_t* img2, int h2,
+                        int w2, int stride2, const float* xy1, const float* xy2, int n, uint8_t* out);
+
 /* SIFT extraction ---------------------------------------------------------- */
 typedef struct imatch_sift_params {
     int n_octave_layers;       /* nOctaveLayers_sift   (MF:31), OpenCV default 3 */

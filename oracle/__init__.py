@@ -299,3 +299,30 @@ def undistort(img, K, D, DIM, balance=0.0, scale=0.5):
     s0, s1 = int((dim1[0] * (1 - scale)) / 2), int((dim1[1] * (1 - scale)) / 2)
     t0, t1 = int(dim1[0] * scale), int(dim1[1] * scale)
     return und[s1:s1 + t1, s0:s0 + t0]
+
+
+# ---- match canvas (draw_oracle.c) ---------------------------------------------------------------
+def _declare_draw(L):
+    c_int = ctypes.c_int
+    L.oracle_draw_matches.argtypes = [_u8p, c_int, c_int, _u8p, c_int, c_int, _f32p, _f32p, c_int, _u8p]
+    L.oracle_draw_matches.restype = None
+
+
+_declare_before_draw = _declare
+
+
+def _declare(L):  # noqa: F811
+    _declare_before_draw(L)
+    _declare_draw(L)
+
+
+def draw_matches(img1, xy1, img2, xy2):
+    """The match canvas of match_finder.py:196 under "Spec D" (draw_oracle.c): xy1[i] <-> xy2[i] are the good matches."""
+    img1 = np.ascontiguousarray(img1, np.uint8)
+    img2 = np.ascontiguousarray(img2, np.uint8)
+    xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
+    xy2 = np.ascontiguousarray(xy2, np.float32).reshape(-1, 2)
+    out = np.empty((max(img1.shape[0], img2.shape[0]), img1.shape[1] + img2.shape[1], 3), np.uint8)
+    lib().oracle_draw_matches(_p(img1, _u8p), img1.shape[0], img1.shape[1], _p(img2, _u8p), img2.shape[0], img2.shape[1],
+                              _p(xy1, _f32p), _p(xy2, _f32p), len(xy1), _p(out, _u8p))
+    return out
