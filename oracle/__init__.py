@@ -326,3 +326,81 @@ def draw_matches(img1, xy1, img2, xy2):
     lib().oracle_draw_matches(_p(img1, _u8p), img1.shape[0], img1.shape[1], _p(img2, _u8p), img2.shape[0], img2.shape[1],
                               _p(xy1, _f32p), _p(xy2, _f32p), len(xy1), _p(out, _u8p))
     return out
+
+
+# ---- AKAZE (akaze_oracle.c) -------------------------------------------------------------------------
+def _declare_akaze(L):
+    c_int, c_vp = ctypes.c_int, ctypes.c_void_p
+    ip = ctypes.POINTER(c_int)
+    L.oracle_akaze_run.argtypes = [_u8p, c_int, c_int, ctypes.c_double, c_int, c_int]
+    L.oracle_akaze_run.restype = c_vp
+    L.oracle_akaze_free.argtypes = [c_vp]
+    L.oracle_akaze_free.restype = None
+    L.oracle_akaze_count.argtypes = [c_vp]
+    L.oracle_akaze_count.restype = c_int
+    L.oracle_akaze_levels.argtypes = [c_vp]
+    L.oracle_akaze_levels.restype = c_int
+    L.oracle_akaze_kcontrast.argtypes = [c_vp]
+    L.oracle_akaze_kcontrast.restype = ctypes.c_float
+    L.oracle_akaze_level_info.argtypes = [c_vp, c_int, ip, ip, ip, ip, ip, _f32p]
+    L.oracle_akaze_level_info.restype = None
+    L.oracle_akaze_get.argtypes = [c_vp, _f32p, _f32p]
+    L.oracle_akaze_get.restype = None
+    L.oracle_akaze_layer.argtypes = [c_vp, c_int, c_int, _f32p]
+    L.oracle_akaze_layer.restype = c_int
+    L.oracle_fed_tau.argtypes = [ctypes.c_float, ctypes.c_float, _f32p]
+    L.oracle_fed_tau.restype = c_int
+    L.oracle_akaze_gauss.argtypes = [_f32p, c_int, c_int, c_int, ctypes.c_double, _f32p]
+    L.oracle_akaze_gauss.restype = None
+
+
+_declare_before_akaze = _declare
+
+
+def _declare(L):  # noqa: F811
+    _declare_before_akaze(L)
+    _declare_akaze(L)
+
+
+class AkazeResult:
+    """kp [K,7] = x, y, size, angle, response, octave, class_id; desc [K,64] f32; levels: list of dicts with
+    rows/cols/sigma_size/border/nsteps/esigma and, when kept, the Lt/Lsmooth/Lx/Ly/Ldet planes."""
+    def __init__(self, kp, desc, kcontrast, levels):
+        self.kp, self.desc, self.kcontrast, self.levels = kp, desc, kcontrast, levels
+
+
+def fed_tau(T, tau_max=0.25):
+    out = np.empty(256, np.float32)
+    n = lib().oracle_fed_tau(float(T), float(tau_max), _p(out, _f32p))
+    return out[:max(n, 0)].copy()
+
+
+def akaze(img, threshold=0.0005, n_octaves=4, n_octave_layers=5, keep_levels=False):
+    """cv2.AKAZE_create(descriptor_type=AKAZE_DESCRIPTOR_KAZE, threshold=threshold, nOctaves=n_octaves,
+    nOctaveLayers=n_octave_layers, diffusivity=KAZE_DIFF_PM_G2).detectAndCompute(img, None) (match_finder.py:210-220)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    L = lib()
+    h = L.oracle_akaze_run(_p(img, _u8p), img.shape[0], img.shape[1], float(threshold), int(n_octaves), int(n_octave_layers))
+    if not h:
+        raise ValueError("oracle.akaze: level sizes must halve exactly (see akaze_oracle.c)")
+    try:
+        n = L.oracle_akaze_count(h)
+        kp = np.empty((n, 7), np.float32)
+        desc = np.empty((n, 64), np.float32)
+        L.oracle_akaze_get(h, _p(kp, _f32p), _p(desc, _f32p))
+        levels = []
+        ci = ctypes.c_int
+        for i in range(L.oracle_akaze_levels(h)):
+            r, c, s, b, ns, es = ci(), ci(), ci(), ci(), ci(), ctypes.c_float()
+            L.oracle_akaze_level_info(h, i, ctypes.byref(r), ctypes.byref(c), ctypes.byref(s), ctypes.byref(b), ctypes.byref(ns),
+                                      ctypes.byref(es))
+            lv = dict(rows=r.value, cols=c.value, sigma_size=s.value, border=b.value, nsteps=ns.value, esigma=es.value)
+            if keep_levels:
+                for kind, name in enumerate(("Lt", "Lsmooth", "Lx", "Ly", "Ldet")):
+                    a = np.empty((r.value, c.value), np.float32)
+                    L.oracle_akaze_layer(h, kind, i, _p(a, _f32p))
+                    lv[name] = a
+            levels.append(lv)
+        return AkazeResult(kp, desc, float(L.oracle_akaze_kcontrast(h)), levels)
+    finally:
+        L.oracle_akaze_free(h)

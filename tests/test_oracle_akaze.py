@@ -1,0 +1,196 @@
+"""CPU checks of the AKAZE oracle (oracle/akaze_oracle.c, "Spec A"; reference call site match_finder.py:210-220):
+independent numpy/scipy statements of its stages and structural properties. Parity with OpenCV itself is unpinned (no
+cv2 here, no fixtures in the reference)."""
+import os
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+import oracle
+from image_matching_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def frame():
+    return np.ascontiguousarray(synth.synth_map(512, seed=3)[16:336, 32:480])   # 320 x 448
+
+
+@pytest.fixture(scope="module")
+def res(frame):
+    return oracle.akaze(frame, keep_levels=True)
+
+
+def test_fed_cycle_sums_to_process_time():
+    for T in (0.409, 1.0, 10.0, 60.0):
+        tau = oracle.fed_tau(T)
+        n = int(np.ceil(np.sqrt(3 * T / 0.25 + 0.25) - 0.5 - 1e-8))
+        assert len(tau) == n and abs(tau.sum() - T) < 1e-4 * T and (tau > 0).all()
+        # the unpermuted steps are 0.25 scale / (2 cos^2(pi (2k + 1) / (4n + 2)))
+        k = np.arange(n)
+        scale = 3 * T / (0.25 * n * (n + 1))
+        want = np.sort(scale * 0.25 / (2 * np.cos(np.pi * (2 * k + 1) / (4 * n + 2)) ** 2))
+        assert np.allclose(np.sort(tau), want, rtol=1e-4)
+
+
+def test_evolution_table(res):
+    lv = res.levels
+    assert len(lv) == 15                                           # 448x320 -> 224x160 -> 112x80, then 56 < 80 stops
+    assert [l["sigma_size"] for l in lv[:5]] == [2, 3, 3, 4, 4] == [l["sigma_size"] for l in lv[5:10]]
+    assert [l["border"] for l in lv[:5]] == [35, 52, 52, 69, 69]
+    assert abs(lv[7]["esigma"] - 1.6 * 2 ** (2 / 5 + 1)) < 1e-5
+    assert lv[0]["nsteps"] == 0 and all(l["nsteps"] > 0 for l in lv[1:])
+    assert (lv[5]["rows"], lv[5]["cols"]) == (160, 224)
+    with pytest.raises(ValueError):
+        oracle.akaze(np.zeros((321, 448), np.uint8))               # 321 -> 160 is not an exact halving
+
+
+def test_first_level_is_the_gaussian(frame, res):
+    f = frame.astype(np.float32) * np.float32(1 / 255.0)
+    x = np.arange(-4, 5)
+    k = np.exp(-x * x / (2 * 1.6 ** 2)); k /= k.sum()
+    want = ndimage.correlate1d(ndimage.correlate1d(f.astype(np.float64), k, axis=1, mode="nearest"), k, axis=0, mode="nearest")
+    assert np.abs(res.levels[0]["Lt"] - want).max() < 2e-6
+    assert np.array_equal(res.levels[0]["Lt"], res.levels[0]["Lsmooth"])
+
+
+def _np_level(prev_lt, kc, tau):
+    """One evolution level in numpy (f64): smooth, Scharr, g2, explicit steps."""
+    x = np.arange(-2, 3)
+    k = np.exp(-x * x / 2.0); k /= k.sum()
+    sm = ndimage.correlate1d(ndimage.correlate1d(prev_lt, k, axis=1, mode="nearest"), k, axis=0, mode="nearest")
+    d, s = np.array([-1.0, 0, 1]), np.array([3.0, 10, 3])
+    gx = ndimage.correlate1d(ndimage.correlate1d(sm, d, axis=1, mode="mirror"), s, axis=0, mode="mirror")
+    gy = ndimage.correlate1d(ndimage.correlate1d(sm, s, axis=1, mode="mirror"), d, axis=0, mode="mirror")
+    g = 1 / (1 + (gx * gx + gy * gy) / kc ** 2)
+    L = prev_lt.copy()
+    for t in tau:
+        acc = np.zeros_like(L)
+        acc[:, :-1] += (g[:, :-1] + g[:, 1:]) * (L[:, 1:] - L[:, :-1])
+        acc[:, 1:] += (g[:, 1:] + g[:, :-1]) * (L[:, :-1] - L[:, 1:])
+        acc[:-1, :] += (g[:-1, :] + g[1:, :]) * (L[1:, :] - L[:-1, :])
+        acc[1:, :] += (g[1:, :] + g[:-1, :]) * (L[:-1, :] - L[1:, :])
+        acc[[0, 0, -1, -1], [0, -1, 0, -1]] = 0
+        L = L + acc * (t * 0.5)
+    return sm, L
+
+
+def test_diffusion_levels_match_numpy(res):
+    lv = res.levels
+    for i in (1, 2, 4):
+        tau = oracle.fed_tau(0.5 * lv[i]["esigma"] ** 2 - 0.5 * lv[i - 1]["esigma"] ** 2)
+        assert len(tau) == lv[i]["nsteps"]
+        sm, L = _np_level(lv[i - 1]["Lt"].astype(np.float64), res.kcontrast, tau)
+        assert np.abs(lv[i]["Lsmooth"] - sm).max() < 2e-6
+        assert np.abs(lv[i]["Lt"] - L).max() < 5e-6
+    # new octave: 2 x 2 mean, contrast factor x 0.75
+    half = lv[4]["Lt"].astype(np.float64).reshape(160, 2, 224, 2).mean(axis=(1, 3))
+    tau = oracle.fed_tau(0.5 * lv[5]["esigma"] ** 2 - 0.5 * lv[4]["esigma"] ** 2)
+    sm, L = _np_level(half, res.kcontrast * 0.75, tau)
+    assert np.abs(lv[5]["Lt"] - L).max() < 5e-6
+    # diffusion keeps the mean (flux form; only the four corners break the symmetry)
+    assert abs(float(lv[4]["Lt"].mean()) - float(lv[0]["Lt"].mean())) < 1e-5
+
+
+def test_contrast_factor(frame, res):
+    f = frame.astype(np.float64) / 255.0
+    x = np.arange(-2, 3)
+    k = np.exp(-x * x / 2.0); k /= k.sum()
+    sm = ndimage.correlate1d(ndimage.correlate1d(f, k, axis=1, mode="nearest"), k, axis=0, mode="nearest")
+    d, s = np.array([-1.0, 0, 1]), np.array([3.0, 10, 3])
+    gx = ndimage.correlate1d(ndimage.correlate1d(sm, d, axis=1, mode="mirror"), s, axis=0, mode="mirror")
+    gy = ndimage.correlate1d(ndimage.correlate1d(sm, s, axis=1, mode="mirror"), d, axis=0, mode="mirror")
+    mod = np.hypot(gx, gy)[1:-1, 1:-1].ravel()
+    hmax = mod.max()
+    hist = np.bincount((mod * (299 / hmax)).astype(int), minlength=300)
+    nthr = int((mod.size - hist[0]) * 0.7)
+    cum = np.concatenate([[0], np.cumsum(hist[1:])])
+    kbin = int(np.argmax(cum >= nthr)) + 1
+    assert abs(res.kcontrast - hmax * kbin / 300) <= hmax / 300 + 1e-6     # same bin up to one boundary flip
+
+
+def test_detector_response_matches_numpy(res):
+    for i in (0, 3, 7):
+        lv = res.levels[i]
+        s = lv["sigma_size"]
+        w = 10.0 / 3.0
+        norm = 1.0 / (2.0 * s * (w + 2.0))
+        dk = np.zeros(2 * s + 1); dk[0], dk[-1] = -1, 1
+        sk = np.zeros(2 * s + 1); sk[0], sk[s], sk[-1] = norm, w * norm, norm
+
+        def dx(a):
+            return ndimage.correlate1d(ndimage.correlate1d(a, dk, axis=1, mode="mirror"), sk, axis=0, mode="mirror")
+
+        def dy(a):
+            return ndimage.correlate1d(ndimage.correlate1d(a, sk, axis=1, mode="mirror"), dk, axis=0, mode="mirror")
+        sm = lv["Lsmooth"].astype(np.float64)
+        lx, ly = dx(sm), dy(sm)
+        det = (dx(lx) * dy(ly) - dy(lx) ** 2) * s ** 4
+        assert np.abs(lv["Lx"] - lx).max() < 1e-6 and np.abs(lv["Ly"] - ly).max() < 1e-6
+        assert np.abs(lv["Ldet"] - det).max() < 1e-6 * max(1.0, np.abs(det).max() / 1e-3)
+
+
+def test_keypoints_are_maxima_inside_the_border(res):
+    kp = res.kp
+    assert len(kp) > 50
+    assert np.allclose(np.linalg.norm(res.desc, axis=1), 1.0, atol=1e-5)
+    for k in kp:
+        lv = res.levels[int(k[6])]
+        ratio = 2.0 ** k[5]
+        x, y = (k[0] - 0.5 * (ratio - 1)) / ratio, (k[1] - 0.5 * (ratio - 1)) / ratio
+        xi, yi = int(round(x)), int(round(y))
+        b = lv["border"]
+        assert b - 1 <= x <= lv["cols"] - b and b - 1 <= y <= lv["rows"] - b
+        win = lv["Ldet"][yi - 1:yi + 2, xi - 1:xi + 2]
+        assert k[4] > 0.0005 and k[4] >= win.max() - 1e-9 or abs(x - xi) > 0.49 or abs(y - yi) > 0.49
+        assert abs(k[2] - 3.0 * lv["esigma"]) < 1e-4 and 0 <= k[3] < 360
+    # class_id (the evolution level) ascends: output order is level, then row, then column
+    assert (np.diff(kp[:, 6]) >= 0).all()
+
+
+def test_blob_is_found_at_its_place_and_scale():
+    h, w = 320, 448
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.full((h, w), 60.0)
+    for cx, cy, s in ((150.3, 120.6, 4.0), (300.0, 200.0, 7.0)):
+        img += 150 * np.exp(-((x - cx) ** 2 + (y - cy) ** 2) / (2 * s * s))
+    r = oracle.akaze(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+    for cx, cy, s in ((150.3, 120.6, 4.0), (300.0, 200.0, 7.0)):
+        d = np.hypot(r.kp[:, 0] - cx, r.kp[:, 1] - cy)
+        assert d.min() < 1.0
+        best = r.kp[d < 1.5]
+        # the response is normalised by the integer sigma_size^4, not by the true scale: a blob answers on several levels
+        assert ((best[:, 2] / 2 > s * 0.3) & (best[:, 2] / 2 < s * 3.0)).any()
+
+
+def test_rotation_by_90_degrees(frame, res):
+    """The pipeline commutes with a quarter turn up to scan-order effects: keypoints map, angles shift by 90 degrees,
+    descriptors agree."""
+    rot = np.ascontiguousarray(np.rot90(frame))          # (x, y) -> (y, W - 1 - x)
+    r2 = oracle.akaze(rot)
+    W = frame.shape[1]
+    hits, da, dd = 0, [], []
+    for k, d in zip(res.kp, res.desc):
+        want = np.array([k[1], W - 1 - k[0]])
+        dist = np.hypot(r2.kp[:, 0] - want[0], r2.kp[:, 1] - want[1]) + 100.0 * (r2.kp[:, 6] != k[6])
+        j = int(np.argmin(dist))
+        if dist[j] < 0.5:
+            hits += 1
+            da.append(abs((r2.kp[j, 3] - k[3] + 90.0 + 180.0) % 360.0 - 180.0))   # the image turned by +90 in (x, y)
+            dd.append(np.linalg.norm(r2.desc[j] - d))
+    n = len(res.kp)
+    assert hits > 0.95 * n, (n, hits)
+    # 90 degrees is 10.5 of the 42 angle slices, so the 7-slice windows of the two runs do not line up: most
+    # orientations agree to a few degrees, some switch window
+    assert np.median(da) < 3.0 and np.percentile(da, 75) < 8.0, np.percentile(da, [50, 75, 90])
+    assert np.median(dd) < 0.08 and np.percentile(dd, 75) < 0.2, np.percentile(dd, [50, 75, 90])
+
+
+def test_golden_fixture():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "akaze_small.npz"))
+    r = oracle.akaze(g["img"], keep_levels=True)
+    assert np.array_equal(r.kp, g["kp"]) and np.array_equal(r.desc, g["desc"])
+    assert np.float32(r.kcontrast) == g["kcontrast"]
+    assert np.array_equal(r.levels[4]["Lt"], g["Lt_4"]) and np.array_equal(r.levels[6]["Ldet"], g["Ldet_6"])
