@@ -4,4 +4,4 @@ Fricodelco/image_matching behind the reference's own `match_finder` API.
 The compute lives in libimatch.so (hand-written HIP, C-ABI in include/imatch.h); this package is
 the ctypes binding plus the host-side mirror of the reference's Python interface.
 """
-from ._lib import Context, Features, ImatchError, SiftParams, load_library  # noqa: F401
+from ._lib import AkazeParams, Context, Features, ImatchError, SiftParams, load_library  # noqa: F401

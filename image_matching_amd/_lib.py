@@ -18,6 +18,17 @@ c_i64 = ctypes.c_int64
 c_vp = ctypes.c_void_p
 
 
+class AkazeParams(ctypes.Structure):
+    """imatch_akaze_params (include/imatch.h); defaults are the reference's call (match_finder.py:200-211)."""
+    _fields_ = [("threshold", ctypes.c_double), ("n_octaves", ctypes.c_int), ("n_octave_layers", ctypes.c_int),
+                ("clahe", ctypes.c_int), ("clahe_clip", ctypes.c_double), ("clahe_tiles_x", ctypes.c_int),
+                ("clahe_tiles_y", ctypes.c_int)]
+
+    def __init__(self, threshold=0.0005, n_octaves=4, n_octave_layers=5, clahe=True, clahe_clip=30.0, clahe_tiles=(8, 8)):
+        super().__init__(float(threshold), int(n_octaves), int(n_octave_layers), 1 if clahe else 0, float(clahe_clip),
+                         int(clahe_tiles[0]), int(clahe_tiles[1]))
+
+
 class ImatchError(RuntimeError):
     pass
 
@@ -64,6 +75,15 @@ SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_int, c_u8p]),
     "imatch_draw_matches": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int, c_u8p]),
+    "imatch_akaze_extract": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.POINTER(AkazeParams), ctypes.POINTER(c_i64)]),
+    "imatch_akaze_extract_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(AkazeParams), ctypes.POINTER(c_i64)]),
+    "imatch_akaze_download": (ctypes.c_int, [c_vp, c_f32p, c_f32p]),
+    "imatch_akaze_image": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int]),
+    "imatch_akaze_debug_levels": (ctypes.c_int, [c_vp]),
+    "imatch_akaze_debug_layer": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.POINTER(ctypes.c_int),
+                                                ctypes.POINTER(ctypes.c_int)]),
     "imatch_sift_extract": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(SiftParams), ctypes.POINTER(c_vp)]),
     "imatch_sift_extract_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -346,6 +366,39 @@ class Context:
                                                      img2.strides[0], _ptr(xy1, c_f32p), _ptr(xy2, c_f32p), len(xy1),
                                                      _ptr(out, c_u8p)))
         return out
+
+    # -- AKAZE ------------------------------------------------------------------------------
+    def akaze_extract(self, img, params=None, image=False):
+        """[CLAHE ->] AKAZE(DESCRIPTOR_KAZE, PM_G2) detectAndCompute -> (kp f32 [K,7], desc f32 [K,64]) and, with
+        image=True, the CLAHE output as the third item."""
+        img = self._gray(img)
+        params = params or AkazeParams()
+        n = c_i64()
+        with self.lock:
+            self._check(self.lib.imatch_akaze_extract(self._h, _ptr(img, c_u8p), img.shape[0], img.shape[1], img.strides[0],
+                                                      ctypes.byref(params), ctypes.byref(n)))
+            kp = np.empty((n.value, 7), np.float32)
+            desc = np.empty((n.value, 64), np.float32)
+            self._check(self.lib.imatch_akaze_download(self._h, _ptr(kp, c_f32p), _ptr(desc, c_f32p)))
+            if not image:
+                return kp, desc
+            out = np.empty(img.shape, np.uint8) if params.clahe else img.copy()
+            if params.clahe:
+                self._check(self.lib.imatch_akaze_image(self._h, _ptr(out, c_u8p), img.shape[0], img.shape[1]))
+        return kp, desc, out
+
+    def akaze_debug_layer(self, kind, level):
+        """Test hook: plane `kind` (0 Lt, 1 Lsmooth, 2 Lx, 3 Ly, 4 Ldet, 5 contrast factor) of evolution level `level`."""
+        r, c = ctypes.c_int(), ctypes.c_int()
+        with self.lock:
+            self._check(self.lib.imatch_akaze_debug_layer(self._h, kind, level, None, ctypes.byref(r), ctypes.byref(c)))
+            out = np.empty((r.value, c.value), np.float32)
+            self._check(self.lib.imatch_akaze_debug_layer(self._h, kind, level, _ptr(out, c_f32p), ctypes.byref(r),
+                                                          ctypes.byref(c)))
+        return out
+
+    def akaze_levels(self):
+        return int(self.lib.imatch_akaze_debug_levels(self._h))
 
     def sift_extract(self, img, params=None):
         """[CLAHE ->] SIFT detectAndCompute; the result is a Features set resident in HBM."""

@@ -1,0 +1,860 @@
+// AKAZE extraction: the detector the checked-in reference runs, match_finder.py:210-211,220
+//   cv2.AKAZE_create(descriptor_type=AKAZE_DESCRIPTOR_KAZE, threshold=0.0005, nOctaves=4, nOctaveLayers=5,
+//                    diffusivity=KAZE_DIFF_PM_G2).detectAndCompute(img, None)
+// "Spec A" (oracle/akaze_oracle.c) stage by stage. The nonlinear scale space is a chain of small f32 stencils over
+// planes resident in HBM (HBM-bound; 4 B read + 4 B write per pixel and stage, 12 B per FED step):
+//   gauss_kernel<N>      N x N Gaussian, BORDER_REPLICATE (9 x 9 from the u8 image, 5 x 5 per level)
+//   flow_kernel          Scharr pair of Lsmooth -> conductivity g2 (or |grad| + its maximum, for the contrast factor)
+//   fed_kernel           one explicit diffusion step Lt' = Lt + tau/2 * div(g grad Lt)
+//   half_kernel          INTER_AREA by 2 at a new octave
+//   deriv1_kernel        Lx, Ly of Lsmooth by the Scharr pair stretched to +- sigma_size
+//   det_kernel           Lxx, Lxy, Lyy from Lx, Ly -> Ldet
+//   candidates_kernel    strict 3 x 3 maxima above the threshold inside the level's border, with their 3 x 3 response
+// Every stencil stages a 64 x 16 tile plus halo in LDS (coalesced 256-byte row pieces), forms the row pass into a
+// second LDS plane and the column pass from it: one ascending-tap fma chain per pass, the oracle's order, so the
+// planes are bit-identical to the oracle's. The candidate filtering of A4 is an order-dependent scan (first neighbour
+// in row-major order wins) over a few thousand points: it runs on the host on the downloaded candidates, as does the
+// 2 x 2 sub-pixel solve; orientation and the M-SURF descriptor run one wavefront per keypoint.
+#include <math.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <new>
+#include <vector>
+#include "common.h"
+#include "preproc.h"
+
+#define AK_MAX_LEVELS 32
+#define AK_MAX_STEPS 256
+#define AK_TW 64
+#define AK_TH 16
+#define AK_MAXR 6
+#define AK_CAND_FLOATS 12   // level, x, y, 9 responses
+
+struct ak_level {
+    int rows, cols, octave, sublevel, sigma_size, border, nsteps;
+    float esigma, etime, ratio;
+    float tau[AK_MAX_STEPS];
+    float *Lt, *Lsmooth, *Lx, *Ly, *Ldet;   // device planes
+};
+
+struct imatch_akaze_state {
+    char* arena;
+    size_t arena_bytes;
+    int h, w, omax, nsub;
+    int n_levels;
+    ak_level lv[AK_MAX_LEVELS];
+    float *tmpA, *tmpB;      // full-size scratch planes
+    uint8_t* img;            // (CLAHE) input
+    void* clahe_scratch;
+    unsigned* hmax;          // device: bits of the largest gradient modulus
+    int* hist;               // device: 300 bins
+    float* kc;               // device: contrast factor per octave
+    int* n_cand;             // device counter
+    float* cand;             // device [cap][AK_CAND_FLOATS]
+    int cand_cap;
+    float* kp_dev;           // device [kp_cap][8]: x, y, size, angle, response, octave, level, pad
+    float* desc_dev;         // device [kp_cap][64]
+    int kp_cap;
+    // last result (host)
+    std::vector<float> kp, desc;
+    int n_kp;
+};
+
+void imatch_akaze_state_free(imatch_ctx* ctx) {
+    if (!ctx || !ctx->akaze) return;
+    if (ctx->akaze->arena) (void)hipFree(ctx->akaze->arena);
+    delete ctx->akaze;
+    ctx->akaze = nullptr;
+}
+
+// ---- fed.cpp (host) ------------------------------------------------------------------------------------------------
+static bool is_prime(int n) {
+    if (n <= 1) return false;
+    if (n == 2 || n == 3 || n == 5 || n == 7) return true;
+    if (n % 2 == 0 || n % 3 == 0 || n % 5 == 0 || n % 7 == 0) return false;
+    const int upper = (int)(sqrt((double)n + 1.0));
+    for (int d = 11; d <= upper; d += 2)
+        if (n % d == 0) return false;
+    return true;
+}
+
+static int fed_tau(float T, float tau_max, float* tau) {
+    const int n = (int)ceilf(sqrtf(3.0f * T / tau_max + 0.25f) - 0.5f - 1.0e-8f);
+    if (n <= 0) return 0;
+    if (n > AK_MAX_STEPS) return -1;
+    const float scale = 3.0f * T / (tau_max * (float)(n * (n + 1)));
+    float tauh[AK_MAX_STEPS];
+    const float c = 1.0f / (4.0f * (float)n + 2.0f), d = scale * tau_max / 2.0f;
+    for (int k = 0; k < n; ++k) {
+        const float h = cosf((float)M_PI * (2.0f * (float)k + 1.0f) * c);
+        tauh[k] = d / (h * h);
+    }
+    const int kappa = n / 2;
+    int prime = n + 1;
+    while (!is_prime(prime)) prime++;
+    for (int k = 0, l = 0; l < n; ++k, ++l) {
+        int index;
+        while ((index = ((k + 1) * kappa) % prime - 1) >= n) k++;
+        tau[l] = tauh[index];
+    }
+    return n;
+}
+
+// ---- tile helpers ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ak_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+__device__ __forceinline__ int ak_border(int p, int len, int reflect) {
+    return reflect ? ak_reflect101(p, len) : min(max(p, 0), len - 1);
+}
+
+struct ak_taps {
+    int n;
+    int off[9];
+    float k[9];
+};
+
+#define AK_IN_W (AK_TW + 2 * AK_MAXR + 1)
+#define AK_IN_H (AK_TH + 2 * AK_MAXR)
+
+// stage the tile of `src` around (x0, y0) with halo R into LDS (f32; u8 sources are scaled by 1/255 as convertTo does)
+template <typename T>
+__device__ __forceinline__ void ak_load_tile(const T* __restrict__ src, int rows, int cols, int x0, int y0, int R, int reflect,
+                                             float (*in)[AK_IN_W]) {
+    const int tw = AK_TW + 2 * R, th = AK_TH + 2 * R;
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+        const int ly = i / tw, lx = i - ly * tw;
+        const int gy = ak_border(y0 - R + ly, rows, reflect), gx = ak_border(x0 - R + lx, cols, reflect);
+        const T v = src[(size_t)gy * cols + gx];
+        in[ly][lx] = sizeof(T) == 1 ? (float)v * (float)(1.0 / 255.0) : (float)v;
+    }
+}
+
+// row pass of the staged tile: tmp[ly][x] for ly in [0, TH + 2R), x in [0, TW)
+__device__ __forceinline__ void ak_row_pass(const float (*in)[AK_IN_W], int R, const ak_taps& kx, float (*tmp)[AK_TW + 1]) {
+    const int th = AK_TH + 2 * R;
+    for (int i = threadIdx.x; i < th * AK_TW; i += 256) {
+        const int ly = i >> 6, x = i & 63;
+        float acc = kx.k[0] * in[ly][x + R + kx.off[0]];
+        for (int t = 1; t < kx.n; ++t) acc = fmaf(kx.k[t], in[ly][x + R + kx.off[t]], acc);
+        tmp[ly][x] = acc;
+    }
+}
+
+__device__ __forceinline__ float ak_col_pass(const float (*tmp)[AK_TW + 1], int R, const ak_taps& ky, int y, int x) {
+    float acc = ky.k[0] * tmp[y + R + ky.off[0]][x];
+    for (int t = 1; t < ky.n; ++t) acc = fmaf(ky.k[t], tmp[y + R + ky.off[t]][x], acc);
+    return acc;
+}
+
+// ---- kernels -----------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+ak_gauss_kernel(const T* __restrict__ src, int rows, int cols, ak_taps k, float* __restrict__ dst, float* __restrict__ dst2) {
+    __shared__ float in[AK_IN_H][AK_IN_W];
+    __shared__ float tmp[AK_IN_H][AK_TW + 1];
+    const int x0 = blockIdx.x * AK_TW, y0 = blockIdx.y * AK_TH, R = k.n / 2;
+    ak_load_tile(src, rows, cols, x0, y0, R, 0, in);
+    __syncthreads();
+    ak_row_pass(in, R, k, tmp);
+    __syncthreads();
+    const int x = threadIdx.x & 63;
+    if (x0 + x >= cols) return;
+    for (int y = threadIdx.x >> 6; y < AK_TH && y0 + y < rows; y += 4) {
+        const float v = ak_col_pass(tmp, R, k, y, x);
+        dst[(size_t)(y0 + y) * cols + x0 + x] = v;
+        if (dst2) dst2[(size_t)(y0 + y) * cols + x0 + x] = v;
+    }
+}
+
+// Scharr pair (unnormalised [-1 0 1] x [3 10 3], BORDER_REFLECT_101). mode 0: conductivity g2 with k = kc[octave];
+// mode 1: gradient modulus of the interior pixels, and its maximum (all moduli are >= 0: their bit patterns order).
+__global__ void __launch_bounds__(256)
+ak_flow_kernel(const float* __restrict__ src, int rows, int cols, const float* __restrict__ kc, int octave, int mode,
+               float* __restrict__ dst, unsigned* __restrict__ hmax) {
+    __shared__ float in[AK_TH + 2][AK_TW + 2 + 1];
+    const int x0 = blockIdx.x * AK_TW, y0 = blockIdx.y * AK_TH;
+    for (int i = threadIdx.x; i < (AK_TH + 2) * (AK_TW + 2); i += 256) {
+        const int ly = i / (AK_TW + 2), lx = i - ly * (AK_TW + 2);
+        in[ly][lx] = src[(size_t)ak_reflect101(y0 - 1 + ly, rows) * cols + ak_reflect101(x0 - 1 + lx, cols)];
+    }
+    __syncthreads();
+    const int x = threadIdx.x & 63;
+    float k2inv = 0.f;
+    if (mode == 0) {
+        const float k = kc[octave];
+        k2inv = 1.0f / (k * k);
+    }
+    float wmax = 0.f;
+    for (int y = threadIdx.x >> 6; y < AK_TH; y += 4) {
+        const int gx_ = x0 + x, gy_ = y0 + y;
+        if (gx_ >= cols || gy_ >= rows) continue;
+        // row passes of the three rows, then the column passes (ascending taps)
+        const float d0 = in[y][x + 2] - in[y][x], d1 = in[y + 1][x + 2] - in[y + 1][x], d2 = in[y + 2][x + 2] - in[y + 2][x];
+        const float gx = fmaf(3.f, d2, fmaf(10.f, d1, 3.f * d0));
+        const float s0 = fmaf(3.f, in[y][x + 2], fmaf(10.f, in[y][x + 1], 3.f * in[y][x]));
+        const float s2 = fmaf(3.f, in[y + 2][x + 2], fmaf(10.f, in[y + 2][x + 1], 3.f * in[y + 2][x]));
+        const float gy = s2 - s0;
+        if (mode == 0) {
+            dst[(size_t)gy_ * cols + gx_] = 1.0f / (1.0f + ((gx * gx + gy * gy) * k2inv));
+        } else {
+            const float m = sqrtf(gx * gx + gy * gy);
+            dst[(size_t)gy_ * cols + gx_] = m;
+            if (gx_ >= 1 && gx_ < cols - 1 && gy_ >= 1 && gy_ < rows - 1) wmax = fmaxf(wmax, m);
+        }
+    }
+    if (mode == 1) {
+        for (int o = 32; o; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+        if ((threadIdx.x & 63) == 0 && wmax > 0.f) atomicMax(hmax, __float_as_uint(wmax));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ak_hist_kernel(const float* __restrict__ modg, int rows, int cols, const unsigned* __restrict__ hmax, int nbins,
+               int* __restrict__ hist) {
+    __shared__ int h[512];
+    for (int i = threadIdx.x; i < nbins; i += 256) h[i] = 0;
+    __syncthreads();
+    const float hm = __uint_as_float(*hmax);
+    if (hm > 0.f) {
+        const float mul = (float)(nbins - 1) / hm;
+        const int total = (rows - 2) * (cols - 2);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+            const int y = i / (cols - 2) + 1, x = i % (cols - 2) + 1;
+            atomicAdd(&h[(int)(modg[(size_t)y * cols + x] * mul)], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += 256)
+        if (h[i]) atomicAdd(hist + i, h[i]);
+}
+
+__global__ void ak_kc_kernel(const int* __restrict__ hist, const unsigned* __restrict__ hmax, int nbins, int total, float perc,
+                             int n_octaves, float* __restrict__ kc) {
+    if (threadIdx.x || blockIdx.x) return;
+    const float hm = __uint_as_float(*hmax);
+    float k = 0.03f;
+    if (hm > 0.f) {
+        const int nthreshold = (int)((total - hist[0]) * perc);
+        int nelements = 0;
+        for (int b = 1; b < nbins; ++b) {
+            if (nelements >= nthreshold) { k = hm * b / nbins; break; }
+            nelements += hist[b];
+        }
+    }
+    for (int o = 0; o < n_octaves; ++o) {
+        kc[o] = k;
+        k *= 0.75f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ak_fed_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, int rows, int cols, float step, float* __restrict__ out) {
+    __shared__ float t[AK_TH + 2][AK_TW + 2 + 1];
+    __shared__ float f[AK_TH + 2][AK_TW + 2 + 1];
+    const int x0 = blockIdx.x * AK_TW, y0 = blockIdx.y * AK_TH;
+    for (int i = threadIdx.x; i < (AK_TH + 2) * (AK_TW + 2); i += 256) {
+        const int ly = i / (AK_TW + 2), lx = i - ly * (AK_TW + 2);
+        const int gy = min(max(y0 - 1 + ly, 0), rows - 1), gx = min(max(x0 - 1 + lx, 0), cols - 1);
+        t[ly][lx] = Lt[(size_t)gy * cols + gx];
+        f[ly][lx] = Lf[(size_t)gy * cols + gx];
+    }
+    __syncthreads();
+    const int x = threadIdx.x & 63, lx = x + 1;
+    const int gx = x0 + x;
+    if (gx >= cols) return;
+    for (int y = threadIdx.x >> 6; y < AK_TH; y += 4) {
+        const int gy = y0 + y, ly = y + 1;
+        if (gy >= rows) break;
+        const bool ex = gx == 0 || gx == cols - 1, ey = gy == 0 || gy == rows - 1;
+        const float tc = t[ly][lx], fc = f[ly][lx];
+        float s;
+        if (ex && ey) {
+            s = 0.f;
+        } else if (!ex && !ey) {
+            s = (fc + f[ly][lx + 1]) * (t[ly][lx + 1] - tc) + (fc + f[ly][lx - 1]) * (t[ly][lx - 1] - tc) +
+                (fc + f[ly + 1][lx]) * (t[ly + 1][lx] - tc) + (fc + f[ly - 1][lx]) * (t[ly - 1][lx] - tc);
+        } else if (ey) {
+            const int lv = gy == 0 ? ly + 1 : ly - 1;
+            s = (fc + f[ly][lx + 1]) * (t[ly][lx + 1] - tc) + (fc + f[ly][lx - 1]) * (t[ly][lx - 1] - tc) +
+                (fc + f[lv][lx]) * (t[lv][lx] - tc);
+        } else {
+            const int ln = gx == 0 ? lx + 1 : lx - 1;
+            s = (fc + f[ly][ln]) * (t[ly][ln] - tc) + (fc + f[ly + 1][lx]) * (t[ly + 1][lx] - tc) +
+                (fc + f[ly - 1][lx]) * (t[ly - 1][lx] - tc);
+        }
+        const float stepv = s * step;
+        out[(size_t)gy * cols + gx] = tc + stepv;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ak_half_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst, int rows, int cols) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const float* s = src + (size_t)(2 * y) * scols + 2 * x;
+    dst[(size_t)y * cols + x] = ((s[0] + s[1]) + (s[scols] + s[scols + 1])) * 0.25f;
+}
+
+// Lx = D_x(src), Ly = D_y(src) with the pair stretched to +- s (sepFilter2D, BORDER_REFLECT_101)
+__global__ void __launch_bounds__(256)
+ak_deriv1_kernel(const float* __restrict__ src, int rows, int cols, int s, ak_taps kd, ak_taps ks, float* __restrict__ Lx,
+                 float* __restrict__ Ly) {
+    __shared__ float in[AK_IN_H][AK_IN_W];
+    __shared__ float tmp[AK_IN_H][AK_TW + 1];
+    const int x0 = blockIdx.x * AK_TW, y0 = blockIdx.y * AK_TH;
+    ak_load_tile(src, rows, cols, x0, y0, s, 1, in);
+    __syncthreads();
+    const int x = threadIdx.x & 63;
+    const bool live = x0 + x < cols;
+    ak_row_pass(in, s, kd, tmp);
+    __syncthreads();
+    if (live)
+        for (int y = threadIdx.x >> 6; y < AK_TH && y0 + y < rows; y += 4)
+            Lx[(size_t)(y0 + y) * cols + x0 + x] = ak_col_pass(tmp, s, ks, y, x);
+    __syncthreads();
+    ak_row_pass(in, s, ks, tmp);
+    __syncthreads();
+    if (live)
+        for (int y = threadIdx.x >> 6; y < AK_TH && y0 + y < rows; y += 4)
+            Ly[(size_t)(y0 + y) * cols + x0 + x] = ak_col_pass(tmp, s, kd, y, x);
+}
+
+// Ldet = (D_x(Lx) D_y(Ly) - D_y(Lx)^2) s^4
+__global__ void __launch_bounds__(256)
+ak_det_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int rows, int cols, int s, ak_taps kd, ak_taps ks,
+              float* __restrict__ Ldet) {
+    __shared__ float in[AK_IN_H][AK_IN_W];
+    __shared__ float tmp[AK_IN_H][AK_TW + 1];
+    const int x0 = blockIdx.x * AK_TW, y0 = blockIdx.y * AK_TH;
+    const int x = threadIdx.x & 63, yb = threadIdx.x >> 6;
+    float lxx[4], lxy[4], lyy[4];
+    ak_load_tile(Lx, rows, cols, x0, y0, s, 1, in);
+    __syncthreads();
+    ak_row_pass(in, s, kd, tmp);
+    __syncthreads();
+    for (int j = 0; j < 4; ++j) lxx[j] = ak_col_pass(tmp, s, ks, yb + 4 * j, x);
+    __syncthreads();
+    ak_row_pass(in, s, ks, tmp);
+    __syncthreads();
+    for (int j = 0; j < 4; ++j) lxy[j] = ak_col_pass(tmp, s, kd, yb + 4 * j, x);
+    __syncthreads();
+    ak_load_tile(Ly, rows, cols, x0, y0, s, 1, in);
+    __syncthreads();
+    ak_row_pass(in, s, ks, tmp);
+    __syncthreads();
+    for (int j = 0; j < 4; ++j) lyy[j] = ak_col_pass(tmp, s, kd, yb + 4 * j, x);
+    const float s4 = (float)(s * s * s * s);
+    if (x0 + x < cols)
+        for (int j = 0; j < 4; ++j) {
+            const int gy = y0 + yb + 4 * j;
+            if (gy < rows) Ldet[(size_t)gy * cols + x0 + x] = (lxx[j] * lyy[j] - lxy[j] * lxy[j]) * s4;
+        }
+}
+
+__global__ void __launch_bounds__(256)
+ak_candidates_kernel(const float* __restrict__ Ldet, int rows, int cols, int border, float thr, int level,
+                     int* __restrict__ n_cand, float* __restrict__ cand, int cap) {
+    const int x = border + blockIdx.x * 64 + (threadIdx.x & 63), y = border + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols - border || y >= rows - border) return;
+    const float* c = Ldet + (size_t)y * cols + x;
+    const float v = *c;
+    if (v <= thr) return;
+    if (v <= c[-1] || v <= c[1]) return;
+    if (v <= c[-cols - 1] || v <= c[-cols] || v <= c[-cols + 1]) return;
+    if (v <= c[cols - 1] || v <= c[cols] || v <= c[cols + 1]) return;
+    const int slot = atomicAdd(n_cand, 1);
+    if (slot >= cap) return;
+    float* o = cand + (size_t)slot * AK_CAND_FLOATS;
+    o[0] = (float)level; o[1] = (float)x; o[2] = (float)y;
+    o[3] = c[-cols - 1]; o[4] = c[-cols]; o[5] = c[-cols + 1];
+    o[6] = c[-1]; o[7] = v; o[8] = c[1];
+    o[9] = c[cols - 1]; o[10] = c[cols]; o[11] = c[cols + 1];
+}
+
+// ---- orientation + descriptor: one wavefront per keypoint -----------------------------------------------------------
+struct ak_levels_dev {
+    int n;
+    int rows[AK_MAX_LEVELS], cols[AK_MAX_LEVELS];
+    float ratio[AK_MAX_LEVELS];
+    const float* Lx[AK_MAX_LEVELS];
+    const float* Ly[AK_MAX_LEVELS];
+};
+
+__device__ __forceinline__ float ak_angle_deg(float y, float x) {
+    float a = atan2f(y, x) * (float)(180.0 / M_PI);
+    if (a < 0) a += 360.f;
+    if (a >= 360.f) a -= 360.f;
+    return a;
+}
+
+__global__ void __launch_bounds__(256)
+ak_orient_kernel(float* __restrict__ kp, int n, ak_levels_dev L) {
+    __shared__ float resX[4][112], resY[4][112];
+    __shared__ unsigned char bin[4][112], order[4][112];
+    __shared__ unsigned char start[4][44];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + w;
+    const bool live = i < n;   // dead waves still reach the barriers
+    float* k = kp + (size_t)(live ? i : 0) * 8;
+    const int lvl = live ? (int)k[6] : 0;
+    const float ratio = L.ratio[lvl];
+    const int rows = L.rows[lvl], cols = L.cols[lvl];
+    const int scale = __float2int_rn(0.5f * k[2] / ratio);
+    const int x0 = __float2int_rn(k[0] / ratio), y0 = __float2int_rn(k[1] / ratio);
+    // the 109 samples with di^2 + dj^2 < 36, enumerated di-major as the table of OpenSURF's gauss25 weights is walked
+    for (int t = lane; t < 169 && live; t += 64) {
+        const int di = t / 13 - 6, dj = t % 13 - 6;
+        if (di * di + dj * dj >= 36) continue;
+        // rank of (di, dj) among the kept samples
+        int r = 0;
+        for (int a = -6; a < di; ++a)
+            for (int b = -6; b <= 6; ++b) r += (a * a + b * b < 36);
+        for (int b = -6; b < dj; ++b) r += (di * di + b * b < 36);
+        const int y = min(max(y0 + dj * scale, 0), rows - 1), x = min(max(x0 + di * scale, 0), cols - 1);
+        const double g = exp(-(double)(di * di + dj * dj) / 12.5) / (2.0 * M_PI * 6.25);
+        const float wgt = (float)(floor(g * 1e8 + 0.5) / 1e8);
+        const float rx = wgt * L.Lx[lvl][(size_t)y * cols + x], ry = wgt * L.Ly[lvl][(size_t)y * cols + x];
+        resX[w][r] = rx;
+        resY[w][r] = ry;
+        const float ang = ak_angle_deg(ry, rx) * (float)(M_PI / 180.0);
+        int b = (int)(ang / (float)(2.0 * M_PI / 42));
+        if (b < 0 || b >= 42) b = 0;
+        bin[w][r] = (unsigned char)b;
+    }
+    __syncthreads();
+    if (lane == 0 && live) {   // counting sort by slice, stable in the sample index
+        int cnt[43];
+        for (int b = 0; b <= 42; ++b) cnt[b] = 0;
+        for (int s = 0; s < 109; ++s) cnt[bin[w][s] + 1]++;
+        for (int b = 0; b < 42; ++b) cnt[b + 1] += cnt[b];
+        for (int b = 0; b <= 42; ++b) start[w][b] = (unsigned char)cnt[b];
+        for (int s = 0; s < 109; ++s) order[w][cnt[bin[w][s]]++] = (unsigned char)s;
+    }
+    __syncthreads();
+    // lane sn sums the window of 7 slices starting at slice sn, in the oracle's order
+    float sx = 0.f, sy = 0.f, norm = -1.f;
+    if (lane < 42 && live) {
+        for (int q = 0; q < 7; ++q) {
+            const int b = (lane + q) % 42;   // sn..41 then 0..: the wrapped windows add the tail first, as the source does
+            for (int p = start[w][b]; p < start[w][b + 1]; ++p) {
+                sx += resX[w][order[w][p]];
+                sy += resY[w][order[w][p]];
+            }
+        }
+        norm = sx * sx + sy * sy;
+    }
+    // first window with the strictly largest norm
+    float best = norm;
+    for (int o = 32; o; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+    const unsigned long long m = __ballot(norm == best && lane < 42);
+    const int win = m ? __ffsll((long long)m) - 1 : 0;
+    const float bx = __shfl(sx, win), by = __shfl(sy, win);
+    if (lane == 0 && live) k[3] = ak_angle_deg(by, bx);
+}
+
+__global__ void __launch_bounds__(256)
+ak_msurf_kernel(const float* __restrict__ kp, int n, ak_levels_dev L, float* __restrict__ desc) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;   // no barriers below
+    const float* k = kp + (size_t)i * 8;
+    const int lvl = (int)k[6], octave = (int)k[5];
+    const int rows = L.rows[lvl], cols = L.cols[lvl];
+    const float* Lx = L.Lx[lvl];
+    const float* Ly = L.Ly[lvl];
+    const float ratio = (float)(1 << octave);
+    const int scale = __float2int_rn(0.5f * k[2] / ratio);
+    const float angle = k[3] * (float)(M_PI / 180.f);
+    const float yf = k[1] / ratio, xf = k[0] / ratio, co = cosf(angle), si = sinf(angle);
+    float vals[4] = {0.f, 0.f, 0.f, 0.f};   // lane t < 64 keeps descriptor value t: (subregion t / 4, component t % 4)
+    float len = 0.f;
+    for (int sr = 0; sr < 16; ++sr) {
+        const int bi = sr >> 2, bj = sr & 3;
+        const int i0 = -12 + 5 * bi, j0 = -12 + 5 * bj;     // i = -8 - 4 + 9 b - 4 b: the source's running index
+        const float cx = 0.5f + bi, cy = 0.5f + bj;
+        const int ky = i0 + 5, kx = j0 + 5;
+        const float xs = xf + (-kx * scale * si + ky * scale * co);
+        const float ys = yf + (kx * scale * co + ky * scale * si);
+        float dx = 0.f, dy = 0.f, mdx = 0.f, mdy = 0.f;
+        for (int t = lane; t < 81; t += 64) {
+            const int kk = i0 + t / 9, l = j0 + t % 9;
+            const float sample_y = yf + (l * scale * co + kk * scale * si);
+            const float sample_x = xf + (-l * scale * si + kk * scale * co);
+            const float sg = 2.5f * scale;
+            const float ex = xs - sample_x, ey = ys - sample_y;
+            const float gauss_s1 = expf(-(ex * ex + ey * ey) / (2.0f * sg * sg));
+            const int y1 = (int)floorf(sample_y), x1 = (int)floorf(sample_x);
+            const int y2 = y1 + 1, x2 = x1 + 1;
+            if (x1 < 0 || y1 < 0 || x2 >= cols || y2 >= rows) continue;
+            const float fx = sample_x - x1, fy = sample_y - y1;
+            const size_t a = (size_t)y1 * cols + x1, b = (size_t)y1 * cols + x2, c = (size_t)y2 * cols + x1, d = (size_t)y2 * cols + x2;
+            const float rx = (1.0f - fx) * (1.0f - fy) * Lx[a] + fx * (1.0f - fy) * Lx[b] + (1.0f - fx) * fy * Lx[c] + fx * fy * Lx[d];
+            const float ry = (1.0f - fx) * (1.0f - fy) * Ly[a] + fx * (1.0f - fy) * Ly[b] + (1.0f - fx) * fy * Ly[c] + fx * fy * Ly[d];
+            const float rry = gauss_s1 * (rx * co + ry * si);
+            const float rrx = gauss_s1 * (-rx * si + ry * co);
+            dx += rrx; dy += rry; mdx += fabsf(rrx); mdy += fabsf(rry);
+        }
+        for (int o = 32; o; o >>= 1) {
+            dx += __shfl_xor(dx, o); dy += __shfl_xor(dy, o); mdx += __shfl_xor(mdx, o); mdy += __shfl_xor(mdy, o);
+        }
+        const float ux = cx - 2.0f, uy = cy - 2.0f;
+        const float g2 = expf(-(ux * ux + uy * uy) / (2.0f * 1.5f * 1.5f));
+        len += (dx * dx + dy * dy + mdx * mdx + mdy * mdy) * g2 * g2;
+        if ((lane >> 2) == sr) {
+            const int comp = lane & 3;
+            vals[0] = (comp == 0 ? dx : comp == 1 ? dy : comp == 2 ? mdx : mdy) * g2;
+        }
+    }
+    const float len_inv = 1.0f / sqrtf(len);
+    desc[(size_t)i * 64 + lane] = vals[0] * len_inv;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+static void gauss_taps(int n, double sigma, ak_taps* k) {
+    const int n2 = (n - 1) / 2;
+    const double scale2x = -0.125 / (sigma * sigma);
+    double vals[16], sum = 0;
+    for (int i = 0, x = 1 - n; i < n2; i++, x += 2) {
+        vals[i] = exp((double)(x * x) * scale2x);
+        sum += vals[i];
+    }
+    sum = sum * 2 + 1.0;
+    const double mul1 = 1.0 / sum;
+    k->n = n;
+    for (int i = 0; i < n2; i++) k->k[i] = k->k[n - 1 - i] = (float)(vals[i] * mul1);
+    k->k[n2] = (float)mul1;
+    for (int i = 0; i < n; ++i) k->off[i] = i - n2;
+}
+
+static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
+    imatch_akaze_state* S = ctx->akaze;
+    if (S && S->h == h && S->w == w && S->omax == omax && S->nsub == nsub) return IMATCH_OK;
+    if (S) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        imatch_akaze_state_free(ctx);
+    }
+    S = new (std::nothrow) imatch_akaze_state();
+    if (!S) return imatch_set_err(ctx, IMATCH_ENOMEM, "host allocation failed");
+    S->arena = nullptr; S->n_levels = 0; S->n_kp = 0;
+    ctx->akaze = S;
+    S->h = h; S->w = w; S->omax = omax; S->nsub = nsub;
+    const float soffset = 1.6f, derivative_factor = 1.5f, smax = 12.0f * sqrtf(2.0f);
+    for (int i = 0, power = 1; i <= omax - 1; ++i, power *= 2) {
+        const float rfactor = 1.0f / power;
+        const int lh = (int)(h * rfactor), lw = (int)(w * rfactor);
+        if ((lw < 80 || lh < 40) && i != 0) break;
+        if (i > 0 && (S->lv[S->n_levels - 1].rows != 2 * lh || S->lv[S->n_levels - 1].cols != 2 * lw)) {
+            imatch_akaze_state_free(ctx);
+            return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: %dx%d does not halve exactly at octave %d (general INTER_AREA "
+                                  "for f32 planes is not implemented)", w, h, i);
+        }
+        for (int j = 0; j < nsub; ++j) {
+            ak_level* e = &S->lv[S->n_levels++];
+            e->rows = lh; e->cols = lw;
+            e->esigma = soffset * powf(2.f, (float)j / (float)nsub + i);
+            e->sigma_size = (int)lrint(e->esigma * derivative_factor / power);
+            e->etime = 0.5f * (e->esigma * e->esigma);
+            e->octave = i; e->sublevel = j; e->ratio = (float)power;
+            e->border = (int)lrint(smax * e->sigma_size) + 1;
+            e->nsteps = 0;
+            if (e->sigma_size > AK_MAXR || e->sigma_size < 1) {
+                imatch_akaze_state_free(ctx);
+                return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: derivative scale %d beyond the tile halo", e->sigma_size);
+            }
+        }
+    }
+    for (int i = 1; i < S->n_levels; ++i) {
+        S->lv[i].nsteps = fed_tau(S->lv[i].etime - S->lv[i - 1].etime, 0.25f, S->lv[i].tau);
+        if (S->lv[i].nsteps < 0) {
+            imatch_akaze_state_free(ctx);
+            return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: FED cycle longer than %d steps", AK_MAX_STEPS);
+        }
+    }
+    // arena
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t px0 = up((size_t)h * w * 4);
+    size_t total = 2 * px0 + up((size_t)h * w) + up(4096 * 1280) + 4096;
+    for (int i = 0; i < S->n_levels; ++i) total += 5 * up((size_t)S->lv[i].rows * S->lv[i].cols * 4);
+    S->cand_cap = std::max(4096, h * w / 16);
+    S->kp_cap = S->cand_cap;
+    total += up((size_t)S->cand_cap * AK_CAND_FLOATS * 4) + up((size_t)S->kp_cap * 8 * 4) + up((size_t)S->kp_cap * 64 * 4);
+    if (hipMalloc((void**)&S->arena, total) != hipSuccess) {
+        S->arena = nullptr;
+        imatch_akaze_state_free(ctx);
+        return imatch_set_err(ctx, IMATCH_ENOMEM, "AKAZE arena of %zu bytes", total);
+    }
+    S->arena_bytes = total;
+    char* p = S->arena;
+    auto take = [&](size_t b) { char* r = p; p += up(b); return r; };
+    S->tmpA = (float*)take(px0); S->tmpB = (float*)take(px0);
+    S->img = (uint8_t*)take((size_t)h * w);
+    S->clahe_scratch = take(4096 * 1280);
+    S->hmax = (unsigned*)take(256);
+    S->hist = (int*)take(2048);
+    S->kc = (float*)take(256);
+    S->n_cand = (int*)take(256);
+    for (int i = 0; i < S->n_levels; ++i) {
+        ak_level* e = &S->lv[i];
+        const size_t b = (size_t)e->rows * e->cols * 4;
+        e->Lt = (float*)take(b); e->Lsmooth = (float*)take(b); e->Lx = (float*)take(b); e->Ly = (float*)take(b);
+        e->Ldet = (float*)take(b);
+    }
+    S->cand = (float*)take((size_t)S->cand_cap * AK_CAND_FLOATS * 4);
+    S->kp_dev = (float*)take((size_t)S->kp_cap * 8 * 4);
+    S->desc_dev = (float*)take((size_t)S->kp_cap * 64 * 4);
+    return IMATCH_OK;
+}
+
+struct ak_cand {
+    int level, x, y;
+    float v[9];
+    bool alive;
+};
+
+// A4 on the candidate list: `pts` of one level sorted by (y, x); returns the first alive point in row-major order inside
+// the window [y - r, y + r) x [x - r, x + r) with squared distance <= r^2
+static int find_neighbor(const std::vector<ak_cand>& c, const std::vector<int>& pts, int x, int y, int r) {
+    auto lo = std::lower_bound(pts.begin(), pts.end(), y - r, [&](int id, int yy) { return c[id].y < yy; });
+    for (auto it = lo; it != pts.end() && c[*it].y < y + r; ++it) {
+        const ak_cand& q = c[*it];
+        if (!q.alive || q.x < x - r || q.x >= x + r) continue;
+        const int dx = q.x - x, dy = q.y - y;
+        if (dx * dx + dy * dy <= r * r) return *it;
+    }
+    return -1;
+}
+
+static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int stride, const imatch_akaze_params* P) {
+    int rc = akaze_prepare(ctx, h, w, P->n_octaves, P->n_octave_layers);
+    if (rc) return rc;
+    imatch_akaze_state* S = ctx->akaze;
+    hipStream_t st = ctx->stream;
+    const uint8_t* src = img_dev;
+    int sstride = stride;
+    if (P->clahe) {
+        rc = imatch_clahe_dev(ctx, img_dev, h, w, stride, P->clahe_clip, P->clahe_tiles_x, P->clahe_tiles_y, S->img, S->clahe_scratch);
+        if (rc) return rc;
+        src = S->img;
+        sstride = w;
+    } else if (stride != w) {
+        HIP_TRY(ctx, hipMemcpy2DAsync(S->img, w, img_dev, stride, w, h, hipMemcpyDeviceToDevice, st));
+        src = S->img;
+        sstride = w;
+    }
+    (void)sstride;
+    auto grid = [](int rows, int cols) { return dim3((cols + AK_TW - 1) / AK_TW, (rows + AK_TH - 1) / AK_TH); };
+    ak_taps g9, g5, kd, ks;
+    gauss_taps(9, 1.6f, &g9);
+    gauss_taps(5, 1.0, &g5);
+    // A2: first level, contrast factor
+    ak_level* e0 = &S->lv[0];
+    hipLaunchKernelGGL((ak_gauss_kernel<uint8_t>), grid(h, w), dim3(256), 0, st, src, h, w, g9, e0->Lsmooth, e0->Lt);
+    if (S->n_levels > 1) {
+        HIP_TRY(ctx, hipMemsetAsync(S->hmax, 0, 256 + 2048, st));   // hmax and the histogram are adjacent
+        hipLaunchKernelGGL((ak_gauss_kernel<uint8_t>), grid(h, w), dim3(256), 0, st, src, h, w, g5, S->tmpA, (float*)nullptr);
+        hipLaunchKernelGGL(ak_flow_kernel, grid(h, w), dim3(256), 0, st, S->tmpA, h, w, S->kc, 0, 1, S->tmpB, S->hmax);
+        const int total = (h - 2) * (w - 2);
+        hipLaunchKernelGGL(ak_hist_kernel, dim3(std::min(1024, (total + 255) / 256)), dim3(256), 0, st, S->tmpB, h, w, S->hmax,
+                           300, S->hist);
+        hipLaunchKernelGGL(ak_kc_kernel, dim3(1), dim3(64), 0, st, S->hist, S->hmax, 300, total, 0.7f, P->n_octaves, S->kc);
+    }
+    for (int i = 1; i < S->n_levels; ++i) {
+        ak_level* e = &S->lv[i];
+        ak_level* p = &S->lv[i - 1];
+        const dim3 g = grid(e->rows, e->cols);
+        const size_t bytes = (size_t)e->rows * e->cols * 4;
+        // the level's starting image: the previous level's final Lt (halved at a new octave); it lands in tmpA or e->Lt
+        // so that the ping-pong of the FED steps ends in e->Lt
+        float* cur = (e->nsteps & 1) ? S->tmpA : e->Lt;
+        float* oth = (e->nsteps & 1) ? e->Lt : S->tmpA;
+        if (e->octave > p->octave)
+            hipLaunchKernelGGL(ak_half_kernel, dim3((e->cols + 63) / 64, (e->rows + 3) / 4), dim3(256), 0, st, p->Lt, p->cols, cur,
+                               e->rows, e->cols);
+        else
+            HIP_TRY(ctx, hipMemcpyAsync(cur, p->Lt, bytes, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL((ak_gauss_kernel<float>), g, dim3(256), 0, st, cur, e->rows, e->cols, g5, e->Lsmooth, (float*)nullptr);
+        hipLaunchKernelGGL(ak_flow_kernel, g, dim3(256), 0, st, e->Lsmooth, e->rows, e->cols, S->kc, e->octave, 0, S->tmpB,
+                           (unsigned*)nullptr);
+        for (int s = 0; s < e->nsteps; ++s) {
+            hipLaunchKernelGGL(ak_fed_kernel, g, dim3(256), 0, st, cur, S->tmpB, e->rows, e->cols, e->tau[s] * 0.5f, oth);
+            std::swap(cur, oth);
+        }
+    }
+    // A3 + candidates
+    HIP_TRY(ctx, hipMemsetAsync(S->n_cand, 0, 4, st));
+    for (int i = 0; i < S->n_levels; ++i) {
+        ak_level* e = &S->lv[i];
+        const int s = e->sigma_size;
+        const float wgt = 10.0f / 3.0f, norm = 1.0f / (2.0f * s * (wgt + 2.0f));
+        kd.n = 2; kd.off[0] = -s; kd.off[1] = s; kd.k[0] = -1.f; kd.k[1] = 1.f;
+        ks.n = 3; ks.off[0] = -s; ks.off[1] = 0; ks.off[2] = s; ks.k[0] = norm; ks.k[1] = wgt * norm; ks.k[2] = norm;
+        const dim3 g = grid(e->rows, e->cols);
+        hipLaunchKernelGGL(ak_deriv1_kernel, g, dim3(256), 0, st, e->Lsmooth, e->rows, e->cols, s, kd, ks, e->Lx, e->Ly);
+        hipLaunchKernelGGL(ak_det_kernel, g, dim3(256), 0, st, e->Lx, e->Ly, e->rows, e->cols, s, kd, ks, e->Ldet);
+        const int iw = e->cols - 2 * e->border, ih = e->rows - 2 * e->border;
+        if (e->border + 1 < e->rows && iw > 0 && ih > 0)
+            hipLaunchKernelGGL(ak_candidates_kernel, dim3((iw + 63) / 64, (ih + 3) / 4), dim3(256), 0, st, e->Ldet, e->rows,
+                               e->cols, e->border, (float)P->threshold, i, S->n_cand, S->cand, S->cand_cap);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    // candidates -> host
+    int n_cand = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_cand, S->n_cand, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (n_cand > S->cand_cap)
+        return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: %d candidates exceed the list of %d", n_cand, S->cand_cap);
+    std::vector<float> raw((size_t)n_cand * AK_CAND_FLOATS);
+    if (n_cand) HIP_TRY(ctx, hipMemcpy(raw.data(), S->cand, raw.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<ak_cand> c((size_t)n_cand);
+    for (int i = 0; i < n_cand; ++i) {
+        const float* r = raw.data() + (size_t)i * AK_CAND_FLOATS;
+        c[i].level = (int)r[0]; c[i].x = (int)r[1]; c[i].y = (int)r[2];
+        memcpy(c[i].v, r + 3, 36);
+        c[i].alive = false;
+    }
+    std::sort(c.begin(), c.end(), [](const ak_cand& a, const ak_cand& b) {
+        return a.level != b.level ? a.level < b.level : (a.y != b.y ? a.y < b.y : a.x < b.x);
+    });
+    std::vector<std::vector<int>> pts((size_t)S->n_levels);
+    for (int i = 0; i < n_cand; ++i) pts[c[i].level].push_back(i);
+    // same level: row-major scan, the first kept neighbour decides
+    for (int i = 0; i < n_cand; ++i) {
+        const int r = S->lv[c[i].level].sigma_size;
+        const int nb = find_neighbor(c, pts[c[i].level], c[i].x, c[i].y, r);
+        if (nb >= 0) {
+            if (c[i].v[4] > c[nb].v[4]) c[nb].alive = false;
+            else continue;
+        }
+        c[i].alive = true;
+    }
+    for (int l = 1; l < S->n_levels; ++l) {   // against the level below
+        const int dr = (int)S->lv[l].ratio / (int)S->lv[l - 1].ratio, r = S->lv[l].sigma_size;
+        for (int id : pts[l])
+            if (c[id].alive) {
+                const int nb = find_neighbor(c, pts[l - 1], c[id].x * dr, c[id].y * dr, r);
+                if (nb >= 0 && c[id].v[4] > c[nb].v[4]) c[nb].alive = false;
+            }
+    }
+    for (int l = S->n_levels - 2; l >= 0; --l) {   // against the level above
+        const int dr = (int)S->lv[l + 1].ratio / (int)S->lv[l].ratio, r = S->lv[l].sigma_size;
+        for (int id : pts[l])
+            if (c[id].alive) {
+                const int nb = find_neighbor(c, pts[l + 1], c[id].x / dr, c[id].y / dr, r);
+                if (nb >= 0 && c[id].v[4] > c[nb].v[4]) c[nb].alive = false;
+            }
+    }
+    // A5
+    S->kp.clear();
+    std::vector<float> kdev;
+    for (int i = 0; i < n_cand; ++i) {
+        if (!c[i].alive) continue;
+        const ak_level* e = &S->lv[c[i].level];
+        const float* v = c[i].v;   // 0 1 2 / 3 4 5 / 6 7 8 = rows y-1, y, y+1
+        const float Dx = 0.5f * (v[5] - v[3]), Dy = 0.5f * (v[7] - v[1]);
+        const float Dxx = v[5] + v[3] - 2.0f * v[4], Dyy = v[7] + v[1] - 2.0f * v[4];
+        const float Dxy = 0.25f * (v[8] + v[0] - v[2] - v[6]);
+        float dx = 0.f, dy = 0.f;
+        double det = (double)Dxx * Dyy - (double)Dxy * Dxy;
+        if (det != 0) {
+            det = 1. / det;
+            dx = (float)(((double)(-Dx) * Dyy - (double)(-Dy) * Dxy) * det);
+            dy = (float)(((double)(-Dy) * Dxx - (double)(-Dx) * Dxy) * det);
+        }
+        if (fabsf(dx) > 1.0f || fabsf(dy) > 1.0f) continue;
+        const float rec[8] = {(c[i].x + dx) * e->ratio + .5f * (e->ratio - 1.0f), (c[i].y + dy) * e->ratio + .5f * (e->ratio - 1.0f),
+                              2.0f * (e->esigma * 1.5f), 0.f, v[4], (float)e->octave, (float)c[i].level, 0.f};
+        kdev.insert(kdev.end(), rec, rec + 8);
+    }
+    const int n = (int)(kdev.size() / 8);
+    S->n_kp = n;
+    S->kp.assign((size_t)n * 7, 0.f);
+    S->desc.assign((size_t)n * 64, 0.f);
+    if (n == 0) return IMATCH_OK;
+    if (n > S->kp_cap) return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: %d keypoints exceed the list of %d", n, S->kp_cap);
+    // A6, A7 on the device
+    ak_levels_dev L;
+    L.n = S->n_levels;
+    for (int i = 0; i < AK_MAX_LEVELS; ++i) {
+        const bool ok = i < S->n_levels;
+        L.rows[i] = ok ? S->lv[i].rows : 1; L.cols[i] = ok ? S->lv[i].cols : 1; L.ratio[i] = ok ? S->lv[i].ratio : 1.f;
+        L.Lx[i] = ok ? S->lv[i].Lx : nullptr; L.Ly[i] = ok ? S->lv[i].Ly : nullptr;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(S->kp_dev, kdev.data(), kdev.size() * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ak_orient_kernel, dim3((n + 3) / 4), dim3(256), 0, st, S->kp_dev, n, L);
+    hipLaunchKernelGGL(ak_msurf_kernel, dim3((n + 3) / 4), dim3(256), 0, st, S->kp_dev, n, L, S->desc_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(kdev.data(), S->kp_dev, kdev.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S->desc.data(), S->desc_dev, (size_t)n * 64 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) memcpy(S->kp.data() + (size_t)i * 7, kdev.data() + (size_t)i * 8, 28);
+    return IMATCH_OK;
+}
+
+extern "C" {
+
+int imatch_akaze_extract_dev(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int stride, const imatch_akaze_params* params,
+                             int64_t* n_out) {
+    if (!ctx || !img_dev || !params || !n_out || h < 3 || w < 3 || stride < w || params->n_octaves < 1 ||
+        params->n_octave_layers < 1 || params->n_octaves * params->n_octave_layers > AK_MAX_LEVELS ||
+        (params->clahe && (params->clahe_tiles_x <= 0 || params->clahe_tiles_y <= 0 ||
+                           params->clahe_tiles_x * params->clahe_tiles_y > 4096)))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = akaze_run(ctx, img_dev, h, w, stride, params);
+    if (rc) return rc;
+    *n_out = ctx->akaze->n_kp;
+    return IMATCH_OK;
+}
+
+int imatch_akaze_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, const imatch_akaze_params* params,
+                         int64_t* n_out) {
+    if (!ctx || !img || h < 3 || w < 3 || stride < w) return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = imatch_ws_reserve(ctx, (size_t)h * w);
+    if (rc) return rc;
+    rc = imatch_stage_upload(ctx, img, h, w, stride, (uint8_t*)ctx->ws);
+    if (rc) return rc;
+    return imatch_akaze_extract_dev(ctx, (const uint8_t*)ctx->ws, h, w, w, params, n_out);
+}
+
+int imatch_akaze_download(imatch_ctx* ctx, float* kp, float* desc) {
+    if (!ctx || !ctx->akaze) return imatch_set_err(ctx, IMATCH_EINVAL, "no AKAZE extraction on this context");
+    const imatch_akaze_state* S = ctx->akaze;
+    if (kp && S->n_kp) memcpy(kp, S->kp.data(), (size_t)S->n_kp * 7 * 4);
+    if (desc && S->n_kp) memcpy(desc, S->desc.data(), (size_t)S->n_kp * 64 * 4);
+    return IMATCH_OK;
+}
+
+int imatch_akaze_image(imatch_ctx* ctx, uint8_t* out, int h, int w) {
+    if (!ctx || !ctx->akaze || !out || ctx->akaze->h != h || ctx->akaze->w != w)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "no AKAZE extraction of that size on this context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->akaze->img, (size_t)h * w, hipMemcpyDeviceToHost));
+    return IMATCH_OK;
+}
+
+int imatch_akaze_debug_levels(imatch_ctx* ctx) { return ctx && ctx->akaze ? ctx->akaze->n_levels : 0; }
+
+int imatch_akaze_debug_layer(imatch_ctx* ctx, int kind, int level, float* out, int* rows, int* cols) {
+    if (!ctx || !ctx->akaze || level < 0 || level >= ctx->akaze->n_levels || kind < 0 || kind > 5)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    const ak_level* e = &ctx->akaze->lv[level];
+    if (kind == 5) {   // the contrast factor of the level's octave, as a 1 x 1 plane
+        if (rows) *rows = 1;
+        if (cols) *cols = 1;
+        if (out) HIP_TRY(ctx, hipMemcpy(out, ctx->akaze->kc + e->octave, 4, hipMemcpyDeviceToHost));
+        return IMATCH_OK;
+    }
+    if (rows) *rows = e->rows;
+    if (cols) *cols = e->cols;
+    if (!out) return IMATCH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const float* src = kind == 0 ? e->Lt : kind == 1 ? e->Lsmooth : kind == 2 ? e->Lx : kind == 3 ? e->Ly : e->Ldet;
+    HIP_TRY(ctx, hipMemcpy(out, src, (size_t)e->rows * e->cols * 4, hipMemcpyDeviceToHost));
+    return IMATCH_OK;
+}
+
+}  // extern "C"

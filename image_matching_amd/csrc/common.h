@@ -26,6 +26,7 @@ struct imatch_ctx {
     // SIFT pyramid arena of the last extraction (kept for reuse by the next frame of the same size)
     struct imatch_sift_state* sift;
     struct imatch_workers* workers;   // host worker pool, created on first use
+    struct imatch_akaze_state* akaze;     // AKAZE arena and last result (akaze.hip)
     struct imatch_camera_state* camera;   // rectification maps of the last calibration (camera.hip)
     // device blocks handed out by imatch_pool_alloc; freed blocks are kept for the next call
     struct imatch_pool_block* pool;
@@ -66,6 +67,7 @@ int imatch_features_pack_u8_seg_dev(imatch_ctx* ctx, imatch_features* f, const u
                                     size_t zs);
 void imatch_sift_state_free(imatch_ctx* ctx);
 void imatch_camera_state_free(imatch_ctx* ctx);
+void imatch_akaze_state_free(imatch_ctx* ctx);
 int imatch_set_err(imatch_ctx* ctx, int code, const char* fmt, ...);
 int imatch_ws_reserve(imatch_ctx* ctx, size_t bytes);
 // Per-context device block pool: a frame's descriptor set, image copy and result lists come from here,

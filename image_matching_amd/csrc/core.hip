@@ -258,6 +258,7 @@ void imatch_destroy(imatch_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     imatch_sift_state_free(ctx);
     imatch_camera_state_free(ctx);
+    imatch_akaze_state_free(ctx);
     imatch_pool_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     imatch_workers_destroy(ctx);

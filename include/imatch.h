@@ -151,6 +151,35 @@ int imatch_features_image(const imatch_features* f, uint8_t* out, int h, int w);
 int imatch_sift_debug_layer(imatch_ctx* ctx, int kind, int o, int i, float* out, int* rows, int* cols);
 int imatch_sift_debug_octaves(imatch_ctx* ctx);
 
+/* AKAZE extraction --------------------------------------- */
+typedef struct imatch_akaze_params {
+    double threshold;          /* 0.0005 (MF:210) */
+    int n_octaves;             /* 4 */
+    int n_octave_layers;       /* 5 */
+    int clahe;                 /* 1: apply CLAHE first, as find_kp_dp does (MF:200-203) */
+    double clahe_clip;         /* 30.0 */
+    int clahe_tiles_x, clahe_tiles_y; /* 8, 8 */
+} imatch_akaze_params;
+
+/* Replaces find_kp_dp's body as checked in (MF:199-221 with the AKAZE call of MF:210-211):
+ * [CLAHE ->] cv2.AKAZE_create(descriptor_type=AKAZE_DESCRIPTOR_KAZE, threshold, nOctaves, nOctaveLayers,
+ * diffusivity=KAZE_DIFF_PM_G2).detectAndCompute(img, None). The result stays with the context until the next
+ * extraction: *n_out keypoints, fetched with imatch_akaze_download. The image's sides must halve exactly at every
+ * octave (multiples of 2^(octaves-1)), else IMATCH_ESIZE. */
+int imatch_akaze_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, const imatch_akaze_params* params,
+                         int64_t* n_out);
+int imatch_akaze_extract_dev(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int stride,
+                             const imatch_akaze_params* params, int64_t* n_out);
+/* kp: [n][7] = x, y, size, angle, response, octave, class_id (cv2.KeyPoint fields; class_id is the evolution level, as
+ * OpenCV leaves it); desc: [n][64] f32, unit length (M-SURF). Either pointer may be null. */
+int imatch_akaze_download(imatch_ctx* ctx, float* kp, float* desc);
+/* The image find_kp_dp returns (MF:221): the CLAHE output of the last AKAZE extraction, [h][w] u8. */
+int imatch_akaze_image(imatch_ctx* ctx, uint8_t* out, int h, int w);
+/* Test hooks (no reference counterpart): number of evolution levels of the last extraction, and one of its planes
+ * (kind 0 Lt, 1 Lsmooth, 2 Lx, 3 Ly, 4 Ldet; 5: the contrast factor of the level's octave as a 1 x 1 plane). */
+int imatch_akaze_debug_levels(imatch_ctx* ctx);
+int imatch_akaze_debug_layer(imatch_ctx* ctx, int kind, int level, float* out, int* rows, int* cols);
+
 /* Brute-force kNN, k = 2 --------------------------------------------------- */
 /* Replaces cv2.BFMatcher(cv2.NORM_L2).knnMatch(q, t, k=2) (MF:182-183) and the cv2.cuda
  * matcher (MF:185-189). idx/dist are [Q][2]; a missing neighbour (N < 2) has idx -1, dist +inf.

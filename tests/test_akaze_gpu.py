@@ -1,0 +1,75 @@
+"""GPU parity of the AKAZE path (csrc/akaze.hip) with the CPU oracle ("Spec A", oracle/akaze_oracle.c), through the
+C-ABI. Bars: the scale space, the derivative planes and the detector response are bit-exact (same f32 operation order,
+correctly rounded division and square root on both sides); keypoint position/size/response/level identical;
+orientation within 0.01 degree and descriptors within L2 1e-4 for >= 99 % of keypoints (atan2f / expf / sincosf differ
+in the last place between libm and the device library, which can move a sample across an angle slice)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from image_matching_amd import AkazeParams, ImatchError, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _compare(ctx, img, planes=True):
+    want = oracle.akaze(img, keep_levels=planes)
+    kp, desc = ctx.akaze_extract(img, AkazeParams(clahe=False))
+    if planes:
+        assert ctx.akaze_levels() == len(want.levels)
+        assert ctx.akaze_debug_layer(5, 0)[0, 0] == np.float32(want.kcontrast)
+        for i, lv in enumerate(want.levels):
+            for kind, name in enumerate(("Lt", "Lsmooth", "Lx", "Ly", "Ldet")):
+                got = ctx.akaze_debug_layer(kind, i)
+                assert np.array_equal(got, lv[name]), (i, name, float(np.abs(got - lv[name]).max()))
+    assert len(kp) == len(want.kp)
+    assert np.array_equal(kp[:, [0, 1, 2, 4, 5, 6]], want.kp[:, [0, 1, 2, 4, 5, 6]])
+    if len(kp):
+        da = np.abs((kp[:, 3] - want.kp[:, 3] + 180.0) % 360.0 - 180.0)
+        dd = np.linalg.norm(desc - want.desc, axis=1)
+        same = da < 0.01
+        assert same.mean() >= 0.99, (same.mean(), np.sort(da)[-5:])
+        assert (dd[same] < 1e-4).mean() >= 0.99, np.sort(dd[same])[-5:]
+        assert np.allclose(np.linalg.norm(desc, axis=1), 1.0, atol=1e-5)
+    return kp, desc
+
+
+def test_frame_640x480_all_planes(ctx):
+    img = np.ascontiguousarray(synth.synth_map(1024, seed=3)[100:580, 200:840])
+    kp, _ = _compare(ctx, img)
+    assert len(kp) > 100
+
+
+def test_other_sizes(ctx):
+    m = synth.synth_map(1024, seed=9)
+    for h, w in ((240, 320), (88, 200), (360, 648), (1024, 1024)):
+        _compare(ctx, np.ascontiguousarray(m[:h, :w]), planes=(h < 500))
+
+
+def test_flat_and_tiny_images(ctx):
+    kp, desc = ctx.akaze_extract(np.full((120, 160), 77, np.uint8), AkazeParams(clahe=False))
+    assert kp.shape == (0, 7) and desc.shape == (0, 64)
+    _compare(ctx, np.random.default_rng(1).integers(0, 256, (48, 64), dtype=np.uint8))   # one octave, no room inside the border
+    with pytest.raises(ImatchError):
+        ctx.akaze_extract(np.zeros((321, 448), np.uint8))      # 321 does not halve exactly
+
+
+def test_clahe_first_as_find_kp_dp(ctx):
+    """find_kp_dp applies CLAHE(30, (8, 8)) before the detector and returns the equalised image (MF:200-203,221)."""
+    img = np.ascontiguousarray(synth.synth_map(512, seed=4)[:240, :320])
+    kp, desc, out = ctx.akaze_extract(img, AkazeParams(), image=True)
+    eq = oracle.clahe(img, 30.0, (8, 8))
+    assert np.array_equal(out, eq)
+    want = oracle.akaze(eq)
+    assert np.array_equal(kp[:, [0, 1, 2, 4, 5, 6]], want.kp[:, [0, 1, 2, 4, 5, 6]])
+
+
+def test_golden_fixture(ctx):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "akaze_small.npz"))
+    kp, desc = ctx.akaze_extract(g["img"], AkazeParams(clahe=False))
+    assert np.array_equal(kp[:, [0, 1, 2, 4, 5, 6]], g["kp"][:, [0, 1, 2, 4, 5, 6]])
+    assert np.array_equal(ctx.akaze_debug_layer(0, 4), g["Lt_4"]) and np.array_equal(ctx.akaze_debug_layer(4, 6), g["Ldet_6"])
+    assert np.median(np.linalg.norm(desc - g["desc"], axis=1)) < 1e-5
