@@ -75,6 +75,7 @@ SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_int, c_u8p]),
     "imatch_draw_matches": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int, c_u8p]),
+    "imatch_knn2_f32": (ctypes.c_int, [c_vp, c_f32p, c_i64, c_f32p, c_i64, ctypes.c_int, c_i32p, c_f32p]),
     "imatch_akaze_extract": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.POINTER(AkazeParams), ctypes.POINTER(c_i64)]),
     "imatch_akaze_extract_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -386,6 +387,19 @@ class Context:
             if params.clahe:
                 self._check(self.lib.imatch_akaze_image(self._h, _ptr(out, c_u8p), img.shape[0], img.shape[1]))
         return kp, desc, out
+
+    def knn2_f32(self, q, t):
+        """BFMatcher(NORM_L2).knnMatch(q, t, k=2) for float descriptors -> (idx int32 [Q,2], dist f32 [Q,2])."""
+        q = np.ascontiguousarray(q, np.float32)
+        t = np.ascontiguousarray(t, np.float32)
+        d = q.shape[1] if q.ndim == 2 else (t.shape[1] if t.ndim == 2 else 64)
+        q, t = q.reshape(-1, d), t.reshape(-1, d)
+        idx = np.empty((len(q), 2), np.int32)
+        dist = np.empty((len(q), 2), np.float32)
+        with self.lock:
+            self._check(self.lib.imatch_knn2_f32(self._h, _ptr(q, c_f32p), len(q), _ptr(t, c_f32p), len(t), d,
+                                                 _ptr(idx, c_i32p), _ptr(dist, c_f32p)))
+        return idx, dist
 
     def akaze_debug_layer(self, kind, level):
         """Test hook: plane `kind` (0 Lt, 1 Lsmooth, 2 Lx, 3 Ly, 4 Ldet, 5 contrast factor) of evolution level `level`."""

@@ -1,0 +1,141 @@
+// Brute-force kNN (k = 2) for float descriptors of any length up to 128 -- the matcher of the AKAZE path (SURVEY 8f
+// rank 3): cv2.BFMatcher(cv2.NORM_L2).knnMatch(descriptors_1, roi.dp, k=2) (match_finder.py:182-183) on the 64-float
+// M-SURF descriptors the checked-in detector produces. These are not small integers, so the bf16 MFMA kernel of knn.hip
+// (exact only for 0..255 values) does not apply; this one computes sum_k (q_k - t_k)^2 in f32 in index order, one
+// sequential chain per pair -- the order of oracle_knn2 -- so distances, indices and ties are bit-identical to the oracle.
+// fp32 VALU-bound: 3 instructions per pair and dimension, operands from LDS tiles stored dimension-major.
+#include <math.h>
+#include "common.h"
+
+#define KF_TQ 64
+#define KF_TT 64
+
+struct kf_top2 { float d1, d2; int j1, j2; };
+
+__device__ __forceinline__ void kf_insert(kf_top2& b, float dd, int j) {   // (dist, index) lexicographic
+    if (dd < b.d1 || (dd == b.d1 && j < b.j1)) { b.d2 = b.d1; b.j2 = b.j1; b.d1 = dd; b.j1 = j; }
+    else if (dd < b.d2 || (dd == b.d2 && j < b.j2)) { b.d2 = dd; b.j2 = j; }
+}
+
+// grid (query tiles, train chunks); partial: [chunk][nq] of kf_top2
+__global__ void __launch_bounds__(256)
+knn2_f32_kernel(const float* __restrict__ q, int64_t nq, const float* __restrict__ t, int64_t nt, int d, int tiles_per_chunk,
+                kf_top2* __restrict__ partial) {
+    extern __shared__ float lds[];
+    float* qs = lds;                      // [d][64]
+    float* ts = lds + (size_t)d * KF_TQ;  // [d][64]
+    const int tid = threadIdx.x, tq = tid & 15, tt = tid >> 4;
+    const int64_t q0 = (int64_t)blockIdx.x * KF_TQ;
+    for (int i = tid; i < KF_TQ * d; i += 256) {
+        const int r = i / d, k = i - r * d;
+        qs[k * KF_TQ + r] = q0 + r < nq ? q[(q0 + r) * d + k] : 0.f;
+    }
+    kf_top2 best[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { best[a].d1 = best[a].d2 = INFINITY; best[a].j1 = best[a].j2 = -1; }
+    const int64_t tile0 = (int64_t)blockIdx.y * tiles_per_chunk;
+    for (int ti = 0; ti < tiles_per_chunk; ++ti) {
+        const int64_t t0 = (tile0 + ti) * KF_TT;
+        if (t0 >= nt) break;
+        __syncthreads();
+        for (int i = tid; i < KF_TT * d; i += 256) {
+            const int r = i / d, k = i - r * d;
+            ts[k * KF_TT + r] = t0 + r < nt ? t[(t0 + r) * d + k] : 0.f;
+        }
+        __syncthreads();
+        float s[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s[a][b] = 0.f;
+        for (int k = 0; k < d; ++k) {
+            const float4 qa = *(const float4*)(qs + k * KF_TQ + tq * 4);
+            const float4 tb = *(const float4*)(ts + k * KF_TT + tt * 4);
+            const float qv[4] = {qa.x, qa.y, qa.z, qa.w}, tv[4] = {tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float e = qv[a] - tv[b];
+                    s[a][b] += e * e;
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {   // ascending train index within the thread
+            const int64_t j = t0 + tt * 4 + b;
+            if (j < nt) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) kf_insert(best[a], sqrtf(s[a][b]), (int)j);
+            }
+        }
+    }
+    // merge the 16 lists of each query
+    __syncthreads();
+    kf_top2* m = (kf_top2*)lds;   // [64 queries][16]
+#pragma unroll
+    for (int a = 0; a < 4; ++a) m[(tq * 4 + a) * 16 + tt] = best[a];
+    __syncthreads();
+    if (tid < KF_TQ && q0 + tid < nq) {
+        kf_top2 r = m[tid * 16];
+        for (int i = 1; i < 16; ++i) {
+            const kf_top2 o = m[tid * 16 + i];
+            if (o.j1 >= 0) kf_insert(r, o.d1, o.j1);
+            if (o.j2 >= 0) kf_insert(r, o.d2, o.j2);
+        }
+        partial[(int64_t)blockIdx.y * nq + q0 + tid] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+knn2_f32_finish_kernel(const kf_top2* __restrict__ partial, int n_chunks, int64_t nq, int* __restrict__ idx, float* __restrict__ dist) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    kf_top2 r = partial[i];
+    for (int c = 1; c < n_chunks; ++c) {
+        const kf_top2 o = partial[(int64_t)c * nq + i];
+        if (o.j1 >= 0) kf_insert(r, o.d1, o.j1);
+        if (o.j2 >= 0) kf_insert(r, o.d2, o.j2);
+    }
+    idx[2 * i] = r.j1; idx[2 * i + 1] = r.j2;
+    dist[2 * i] = r.d1; dist[2 * i + 1] = r.d2;
+}
+
+extern "C" int imatch_knn2_f32(imatch_ctx* ctx, const float* q, int64_t nq, const float* t, int64_t nt, int d, int32_t* idx,
+                               float* dist) {
+    if (!ctx || nq < 0 || nt < 0 || d < 1 || d > 128 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    if (nq > INT32_MAX / 2 || nt > INT32_MAX / 2) return imatch_set_err(ctx, IMATCH_ESIZE, "set too large");
+    if (nq == 0) return IMATCH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n_tiles = (nt + KF_TT - 1) / KF_TT;
+    const int q_tiles = (int)((nq + KF_TQ - 1) / KF_TQ);
+    int n_chunks = (int)std::min<int64_t>(std::max<int64_t>(1, (2048 + q_tiles - 1) / q_tiles), std::max<int64_t>(1, n_tiles / 4));
+    n_chunks = std::min(n_chunks, 1024);
+    const int tiles_per_chunk = (int)std::max<int64_t>(1, (n_tiles + n_chunks - 1) / n_chunks);
+    n_chunks = (int)std::max<int64_t>(1, (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t bq = up((size_t)nq * d * 4), bt = up((size_t)std::max<int64_t>(nt, 1) * d * 4);
+    const size_t bp = up((size_t)n_chunks * nq * sizeof(kf_top2)), bi = up((size_t)nq * 8), bd = up((size_t)nq * 8);
+    int rc = imatch_ws_reserve(ctx, bq + bt + bp + bi + bd);
+    if (rc) return rc;
+    char* p = (char*)ctx->ws;
+    float* qd = (float*)p; p += bq;
+    float* td = (float*)p; p += bt;
+    kf_top2* part = (kf_top2*)p; p += bp;
+    int* idx_d = (int*)p; p += bi;
+    float* dist_d = (float*)p;
+    rc = imatch_hs_reserve(ctx, bq + bt);
+    if (rc) return rc;
+    memcpy(ctx->hs, q, (size_t)nq * d * 4);
+    if (nt) memcpy((char*)ctx->hs + bq, t, (size_t)nt * d * 4);
+    HIP_TRY(ctx, hipMemcpyAsync(qd, ctx->hs, bq + (nt ? (size_t)nt * d * 4 : 0), hipMemcpyHostToDevice, ctx->stream));
+    const size_t lds = std::max((size_t)2 * d * 64 * 4, (size_t)64 * 16 * sizeof(kf_top2));
+    hipLaunchKernelGGL(knn2_f32_kernel, dim3(q_tiles, n_chunks), dim3(256), lds, ctx->stream, qd, nq, td, nt, d, tiles_per_chunk, part);
+    hipLaunchKernelGGL(knn2_f32_finish_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream, part, n_chunks, nq,
+                       idx_d, dist_d);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(idx, idx_d, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dist, dist_d, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return IMATCH_OK;
+}

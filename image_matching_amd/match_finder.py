@@ -20,7 +20,7 @@ from decimal import Decimal
 import numpy as np
 
 from . import draw
-from ._lib import SiftParams
+from ._lib import AkazeParams, SiftParams
 from .cvtypes import DeviceDescriptors, GoodMatches, KeyPoints
 from .geodetic_conv import GeodeticConvert
 from .params import get_param
@@ -47,7 +47,13 @@ def _features_of(ctx, dp):
 
 
 class match_finder():
-    def __init__(self, ctx=None):
+    def __init__(self, ctx=None, detector="sift"):
+        # "sift": the detector north_star names (the commented call of match_finder.py:205-209); "akaze": the call the
+        # checked-in file makes (match_finder.py:210-211). Everything downstream is the same code.
+        if detector not in ("sift", "akaze"):
+            raise ValueError("detector must be 'sift' or 'akaze'")
+        self.detector = detector
+        self.akaze_threshold, self.akaze_octaves, self.akaze_layers = 0.0005, 4, 5   # match_finder.py:210-211
         # parameters (same keys as the reference, match_finder.py:29-38)
         self.optimal_size_x = get_param("image_size_sift")
         self.points_quality = get_param("points_quality_sift")
@@ -157,12 +163,18 @@ class match_finder():
 
     def find_kp_dp(self, img):
         """-> (keypoints, descriptors, CLAHE'd image), as the reference returns them."""
+        if self.detector == "akaze":
+            rec, desc, out = self.ctx.akaze_extract(img, AkazeParams(self.akaze_threshold, self.akaze_octaves,
+                                                                     self.akaze_layers, clahe=True), image=True)
+            return KeyPoints(rec), desc, out
         f = self.ctx.sift_extract(img, self.sift_params(clahe=True))
         kp = KeyPoints(f.download(descriptors=False)[0])
         return kp, DeviceDescriptors(f), f.image(img.shape[0], img.shape[1])
 
     def knn_match(self, query_dp, train_dp):
         """knnMatch(query, train, k=2) -> (idx int32 [Q,2], dist f32 [Q,2]); (-1, inf) where missing."""
+        if not hasattr(query_dp, "features") and np.ndim(query_dp) == 2 and np.shape(query_dp)[1] != 128:
+            return self.ctx.knn2_f32(query_dp, train_dp)      # float descriptors (AKAZE's 64-float M-SURF)
         return self.ctx.knn2(_features_of(self.ctx, query_dp), _features_of(self.ctx, train_dp))
 
     def find_matches(self, roi, cadr):  # roi, cadr

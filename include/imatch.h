@@ -192,6 +192,11 @@ int imatch_knn2(imatch_ctx* ctx, const imatch_features* q, const imatch_features
  * context's stream; a missing neighbour is (INT32_MAX, -1). */
 int imatch_knn2_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t,
                     int32_t idx_offset, int32_t* out4_dev);
+/* The same query for float descriptors of any length d <= 128 (the 64-float M-SURF descriptors of the AKAZE path,
+ * MF:182-183 with MF:210-211): dist = sqrtf of the f32 sum of squared differences accumulated in index order, ties
+ * to the lower train index. Host pointers; q is [nq][d], t is [nt][d]. */
+int imatch_knn2_f32(imatch_ctx* ctx, const float* q, int64_t nq, const float* t, int64_t nt, int d, int32_t* idx,
+                    float* dist);
 /* Merge step after the all-gather of per-shard top-2 (no reference counterpart: the reference is
  * single-process). in4_dev is int32 [n_lists][Q][4]; picks the two smallest by
  * (ssd, idx) lexicographic order into out4_dev [Q][4]. */

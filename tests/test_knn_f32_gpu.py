@@ -1,0 +1,66 @@
+"""GPU parity of the float kNN (csrc/knn_f32.hip) with oracle_knn2 through the C-ABI: the same f32 sum in index order on
+both sides, so indices, distances and tie-breaks are bit-exact (match_finder.py:182-183 on AKAZE descriptors)."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(n, d, seed):
+    v = np.random.default_rng(seed).normal(size=(n, d)).astype(np.float32)
+    return v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-12).astype(np.float32)
+
+
+@pytest.mark.parametrize("nq,nt,d", [(300, 5000, 64), (1, 1, 64), (5, 2, 64), (64, 63, 64), (65, 65, 64), (130, 4097, 64),
+                                     (77, 1000, 128), (40, 300, 7), (3000, 50000, 64)])
+def test_bit_exact(ctx, nq, nt, d):
+    q, t = _unit(nq, d, nq + d), _unit(nt, d, nt + 1)
+    gi, gd = ctx.knn2_f32(q, t)
+    wi, wd = oracle.knn2(q, t)
+    assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+
+
+def test_empty_and_ties(ctx):
+    q = _unit(10, 64, 1)
+    gi, gd = ctx.knn2_f32(q, np.zeros((0, 64), np.float32))
+    assert (gi == -1).all() and np.isinf(gd).all()
+    gi, gd = ctx.knn2_f32(np.zeros((0, 64), np.float32), q)
+    assert gi.shape == (0, 2)
+    t = _unit(500, 64, 2)
+    t[400] = t[7]; t[123] = t[7]; t[300] = q[3]; t[20] = q[3]      # exact duplicates: the lower train index ranks first
+    q2 = np.vstack([q, t[7:8]])
+    gi, gd = ctx.knn2_f32(q2, t)
+    wi, wd = oracle.knn2(q2, t)
+    assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+    assert tuple(gi[10]) == (7, 123) and tuple(gi[3]) == (20, 300) and gd[3, 0] == 0
+
+
+def test_akaze_chain_through_the_facade(ctx):
+    """find_kp_dp -> find_matches -> find_keypoints_transform with detector='akaze' recovers a planted homography."""
+    from image_matching_amd import synth
+    from image_matching_amd.match_finder import match_finder, roi as roi_t
+    from image_matching_amd.image_processing import image_processing
+    mf = match_finder(ctx, detector="akaze")
+    m = synth.synth_map(2048, seed=5)
+    frame, H = synth.synth_frame(m, 3, size=(480, 640), scale_range=(0.9, 1.1))
+    kp1, dp1, img1 = mf.find_kp_dp(frame)
+    kp2, dp2, img2 = mf.find_kp_dp(m)
+    assert dp1.shape[1] == 64 and len(kp1) == len(dp1) > 50
+    cadr = image_processing(img=img1)
+    cadr.kp, cadr.dp = kp1, dp1
+    r = roi_t(img2, kp2, dp2, 1.0, 0, 0)
+    good, img3 = mf.find_matches(r, cadr)
+    assert len(good) > 10 and img3.shape == (2048, 640 + 2048, 3)
+    # the same good list from the oracle's matcher on the same descriptors
+    wi, wd = oracle.knn2(np.asarray(dp1), np.asarray(dp2))
+    keep = wd[:, 0].astype(np.float64) < mf.points_quality * wd[:, 1].astype(np.float64)
+    assert np.array_equal(good.query_idx, np.nonzero(keep)[0]) and np.array_equal(good.train_idx, wi[keep, 0])
+    out = mf.find_keypoints_transform(good, r, cadr, None)
+    M = out[5]
+    assert M is not None
+    corners = np.array([[0, 0, 1], [639, 0, 1], [639, 479, 1], [0, 479, 1]], np.float64).T
+    a = M @ corners; b = H @ corners
+    err = np.hypot(a[0] / a[2] - b[0] / b[2], a[1] / a[2] - b[1] / b[2])
+    assert err.max() < 2.0, err
