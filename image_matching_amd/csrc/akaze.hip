@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <vector>
 #include "common.h"
@@ -49,6 +50,7 @@ struct imatch_akaze_state {
     unsigned* hmax;          // device: bits of the largest gradient modulus
     int* hist;               // device: 300 bins
     float* kc;               // device: contrast factor per octave
+    float* tau_dev;          // device [levels][AK_MAX_STEPS]: the FED cycles
     int* n_cand;             // device counter
     float* cand;             // device [cap][AK_CAND_FLOATS]
     int cand_cap;
@@ -298,6 +300,101 @@ ak_half_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst
     dst[(size_t)y * cols + x] = ((s[0] + s[1]) + (s[scols] + s[scols + 1])) * 0.25f;
 }
 
+// One whole evolution level of a SMALL plane (rows * cols <= AK_SMALL_PX: 120 x 160 and below, i.e. octaves 2 and 3 of a
+// 640 x 480 frame, which hold 139 of the 192 diffusion steps) in ONE workgroup: the level's image and its conductivity
+// stay in LDS (2 x 75 KB) across the start (copy or halving), the 5 x 5 Gaussian, the Scharr pair and every FED step.
+// Replaces 3 + nsteps launches of a few microseconds of work each; same expressions, so the planes are unchanged.
+#define AK_SMALL_PX 19200
+#define AK_SMALL_PT 19      // pixels per thread at 1024 threads
+__global__ void __launch_bounds__(1024)
+ak_level_small_kernel(const float* __restrict__ prev, int pcols, int halve, int rows, int cols, ak_taps g5,
+                      const float* __restrict__ kc, int octave, int nsteps, const float* __restrict__ tau,
+                      float* __restrict__ Lt, float* __restrict__ Lsmooth) {
+    extern __shared__ float ak_lds[];
+    const int px = rows * cols;
+    float* A = ak_lds;
+    float* F = ak_lds + px;
+    const int tid = threadIdx.x;
+    for (int p = tid; p < px; p += 1024) {
+        const int y = p / cols, x = p - y * cols;
+        if (halve) {
+            const float* s = prev + (size_t)(2 * y) * pcols + 2 * x;
+            A[p] = ((s[0] + s[1]) + (s[pcols] + s[pcols + 1])) * 0.25f;
+        } else {
+            A[p] = prev[p];
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < px; p += 1024) {   // Gaussian row pass -> F
+        const int y = p / cols, x = p - y * cols;
+        float acc = g5.k[0] * A[y * cols + min(max(x + g5.off[0], 0), cols - 1)];
+        for (int t = 1; t < g5.n; ++t) acc = fmaf(g5.k[t], A[y * cols + min(max(x + g5.off[t], 0), cols - 1)], acc);
+        F[p] = acc;
+    }
+    __syncthreads();
+    for (int p = tid; p < px; p += 1024) {   // column pass -> Lsmooth (global: the derivative kernels read it too)
+        const int y = p / cols, x = p - y * cols;
+        float acc = g5.k[0] * F[min(max(y + g5.off[0], 0), rows - 1) * cols + x];
+        for (int t = 1; t < g5.n; ++t) acc = fmaf(g5.k[t], F[min(max(y + g5.off[t], 0), rows - 1) * cols + x], acc);
+        Lsmooth[p] = acc;
+    }
+    __threadfence_block();
+    __syncthreads();
+    {
+        const float k = kc[octave];
+        const float k2inv = 1.0f / (k * k);
+        for (int p = tid; p < px; p += 1024) {   // Scharr pair of Lsmooth -> conductivity in F
+            const int y = p / cols, x = p - y * cols;
+            const int xm = ak_reflect101(x - 1, cols), xp = ak_reflect101(x + 1, cols);
+            const float* r0 = Lsmooth + (size_t)ak_reflect101(y - 1, rows) * cols;
+            const float* r1 = Lsmooth + (size_t)y * cols;
+            const float* r2 = Lsmooth + (size_t)ak_reflect101(y + 1, rows) * cols;
+            const float d0 = r0[xp] - r0[xm], d1 = r1[xp] - r1[xm], d2 = r2[xp] - r2[xm];
+            const float gx = fmaf(3.f, d2, fmaf(10.f, d1, 3.f * d0));
+            const float s0 = fmaf(3.f, r0[xp], fmaf(10.f, r0[x], 3.f * r0[xm]));
+            const float s2 = fmaf(3.f, r2[xp], fmaf(10.f, r2[x], 3.f * r2[xm]));
+            const float gy = s2 - s0;
+            F[p] = 1.0f / (1.0f + ((gx * gx + gy * gy) * k2inv));
+        }
+    }
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const float step = tau[st] * 0.5f;
+        float nv[AK_SMALL_PT];
+#pragma unroll
+        for (int j = 0; j < AK_SMALL_PT; ++j) {
+            const int p = tid + j * 1024;
+            if (p >= px) break;
+            const int y = p / cols, x = p - y * cols;
+            const bool ex = x == 0 || x == cols - 1, ey = y == 0 || y == rows - 1;
+            const float tc = A[p], fc = F[p];
+            float sum;
+            if (ex && ey) {
+                sum = 0.f;
+            } else if (!ex && !ey) {
+                sum = (fc + F[p + 1]) * (A[p + 1] - tc) + (fc + F[p - 1]) * (A[p - 1] - tc) +
+                      (fc + F[p + cols]) * (A[p + cols] - tc) + (fc + F[p - cols]) * (A[p - cols] - tc);
+            } else if (ey) {
+                const int pv = y == 0 ? p + cols : p - cols;
+                sum = (fc + F[p + 1]) * (A[p + 1] - tc) + (fc + F[p - 1]) * (A[p - 1] - tc) + (fc + F[pv]) * (A[pv] - tc);
+            } else {
+                const int pn = x == 0 ? p + 1 : p - 1;
+                sum = (fc + F[pn]) * (A[pn] - tc) + (fc + F[p + cols]) * (A[p + cols] - tc) + (fc + F[p - cols]) * (A[p - cols] - tc);
+            }
+            const float stepv = sum * step;
+            nv[j] = tc + stepv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < AK_SMALL_PT; ++j) {
+            const int p = tid + j * 1024;
+            if (p < px) A[p] = nv[j];
+        }
+        __syncthreads();
+    }
+    for (int p = tid; p < px; p += 1024) Lt[p] = A[p];
+}
+
 // Lx = D_x(src), Ly = D_y(src) with the pair stretched to +- s (sepFilter2D, BORDER_REFLECT_101)
 __global__ void __launch_bounds__(256)
 ak_deriv1_kernel(const float* __restrict__ src, int rows, int cols, int s, ak_taps kd, ak_taps ks, float* __restrict__ Lx,
@@ -358,14 +455,23 @@ __global__ void __launch_bounds__(256)
 ak_candidates_kernel(const float* __restrict__ Ldet, int rows, int cols, int border, float thr, int level,
                      int* __restrict__ n_cand, float* __restrict__ cand, int cap) {
     const int x = border + blockIdx.x * 64 + (threadIdx.x & 63), y = border + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols - border || y >= rows - border) return;
-    const float* c = Ldet + (size_t)y * cols + x;
-    const float v = *c;
-    if (v <= thr) return;
-    if (v <= c[-1] || v <= c[1]) return;
-    if (v <= c[-cols - 1] || v <= c[-cols] || v <= c[-cols + 1]) return;
-    if (v <= c[cols - 1] || v <= c[cols] || v <= c[cols + 1]) return;
-    const int slot = atomicAdd(n_cand, 1);
+    bool hit = false;
+    const float* c = Ldet + (size_t)min(y, rows - 1) * cols + min(x, cols - 1);
+    float v = 0.f;
+    if (x < cols - border && y < rows - border) {
+        v = *c;
+        hit = v > thr && v > c[-1] && v > c[1] && v > c[-cols - 1] && v > c[-cols] && v > c[-cols + 1] && v > c[cols - 1] &&
+              v > c[cols] && v > c[cols + 1];
+    }
+    // one atomic per wavefront reserves the slots of its hits (the list's order is settled on the host)
+    const unsigned long long m = __ballot(hit);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_cand, __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (!hit) return;
+    const int slot = base + __popcll(m & ((1ull << lane) - 1));
     if (slot >= cap) return;
     float* o = cand + (size_t)slot * AK_CAND_FLOATS;
     o[0] = (float)level; o[1] = (float)x; o[2] = (float)y;
@@ -576,7 +682,7 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
     // arena
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t px0 = up((size_t)h * w * 4);
-    size_t total = 2 * px0 + up((size_t)h * w) + up(4096 * 1280) + 4096;
+    size_t total = 2 * px0 + up((size_t)h * w) + up(4096 * 1280) + 4096 + up((size_t)AK_MAX_LEVELS * AK_MAX_STEPS * 4);
     for (int i = 0; i < S->n_levels; ++i) total += 5 * up((size_t)S->lv[i].rows * S->lv[i].cols * 4);
     S->cand_cap = std::max(4096, h * w / 16);
     S->kp_cap = S->cand_cap;
@@ -596,6 +702,7 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
     S->hist = (int*)take(2048);
     S->kc = (float*)take(256);
     S->n_cand = (int*)take(256);
+    S->tau_dev = (float*)take((size_t)AK_MAX_LEVELS * AK_MAX_STEPS * 4);
     for (int i = 0; i < S->n_levels; ++i) {
         ak_level* e = &S->lv[i];
         const size_t b = (size_t)e->rows * e->cols * 4;
@@ -605,26 +712,73 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
     S->cand = (float*)take((size_t)S->cand_cap * AK_CAND_FLOATS * 4);
     S->kp_dev = (float*)take((size_t)S->kp_cap * 8 * 4);
     S->desc_dev = (float*)take((size_t)S->kp_cap * 64 * 4);
+    for (int i = 0; i < S->n_levels; ++i)
+        if (S->lv[i].nsteps > 0)
+            HIP_TRY(ctx, hipMemcpy(S->tau_dev + (size_t)i * AK_MAX_STEPS, S->lv[i].tau, (size_t)S->lv[i].nsteps * 4,
+                                   hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)ak_level_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     2 * AK_SMALL_PX * 4));
     return IMATCH_OK;
 }
 
-struct ak_cand {
-    int level, x, y;
-    float v[9];
-    bool alive;
+// Candidates of one level in scan order (row-major), as parallel arrays with a row index: A4 walks them in the order
+// OpenCV's scan meets them, and its neighbour search looks at 2r rows only.
+struct ak_level_pts {
+    int rows = 0;
+    std::vector<int> row_start;       // rows + 1
+    std::vector<int> x, y;
+    std::vector<float> v;             // 9 responses per point: rows y-1, y, y+1
+    std::vector<uint8_t> alive;
+    // the first alive point in row-major order inside [y - r, y + r) x [x - r, x + r) with squared distance <= r^2
+    int find(int px, int py, int r) const {
+        const int y0 = std::max(py - r, 0), y1 = std::min(py + r, rows);
+        for (int yy = y0; yy < y1; ++yy)
+            for (int p = row_start[yy]; p < row_start[yy + 1]; ++p) {
+                if (x[p] >= px + r) break;
+                if (!alive[p] || x[p] < px - r) continue;
+                const int dx = x[p] - px, dy = yy - py;
+                if (dx * dx + dy * dy <= r * r) return p;
+            }
+        return -1;
+    }
 };
 
-// A4 on the candidate list: `pts` of one level sorted by (y, x); returns the first alive point in row-major order inside
-// the window [y - r, y + r) x [x - r, x + r) with squared distance <= r^2
-static int find_neighbor(const std::vector<ak_cand>& c, const std::vector<int>& pts, int x, int y, int r) {
-    auto lo = std::lower_bound(pts.begin(), pts.end(), y - r, [&](int id, int yy) { return c[id].y < yy; });
-    for (auto it = lo; it != pts.end() && c[*it].y < y + r; ++it) {
-        const ak_cand& q = c[*it];
-        if (!q.alive || q.x < x - r || q.x >= x + r) continue;
-        const int dx = q.x - x, dy = q.y - y;
-        if (dx * dx + dy * dy <= r * r) return *it;
+// raw: n records of AK_CAND_FLOATS in any order -> per level, sorted by (y, x) with a counting sort on y
+static void bucket_candidates(const float* raw, int n, const imatch_akaze_state* S, std::vector<ak_level_pts>& L) {
+    L.assign((size_t)S->n_levels, ak_level_pts());
+    std::vector<int> count((size_t)S->n_levels, 0);
+    for (int i = 0; i < n; ++i) count[(int)raw[(size_t)i * AK_CAND_FLOATS]]++;
+    for (int l = 0; l < S->n_levels; ++l) {
+        ak_level_pts& P = L[l];
+        P.rows = S->lv[l].rows;
+        P.row_start.assign((size_t)P.rows + 1, 0);
+        P.x.resize(count[l]); P.y.resize(count[l]); P.v.resize((size_t)count[l] * 9); P.alive.assign(count[l], 0);
     }
-    return -1;
+    for (int i = 0; i < n; ++i) {
+        const float* r = raw + (size_t)i * AK_CAND_FLOATS;
+        L[(int)r[0]].row_start[(int)r[2] + 1]++;
+    }
+    for (auto& P : L)
+        for (int y = 0; y < P.rows; ++y) P.row_start[y + 1] += P.row_start[y];
+    std::vector<std::vector<int>> fill((size_t)S->n_levels);
+    for (int l = 0; l < S->n_levels; ++l) fill[l].assign(L[l].row_start.begin(), L[l].row_start.end() - 1);
+    for (int i = 0; i < n; ++i) {
+        const float* r = raw + (size_t)i * AK_CAND_FLOATS;
+        ak_level_pts& P = L[(int)r[0]];
+        const int yy = (int)r[2], xx = (int)r[1];
+        // insertion by x inside the row (rows hold a handful of points)
+        int p = fill[(int)r[0]][yy]++;
+        while (p > P.row_start[yy] && P.x[p - 1] > xx) {
+            P.x[p] = P.x[p - 1];
+            memcpy(&P.v[(size_t)p * 9], &P.v[(size_t)(p - 1) * 9], 36);
+            --p;
+        }
+        P.x[p] = xx; P.y[p] = yy;
+        memcpy(&P.v[(size_t)p * 9], r + 3, 36);
+    }
+    for (auto& P : L)   // y follows from the row index (the insertion above only moved x and v)
+        for (int yy = 0; yy < P.rows; ++yy)
+            for (int p = P.row_start[yy]; p < P.row_start[yy + 1]; ++p) P.y[p] = yy;
 }
 
 static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int stride, const imatch_akaze_params* P) {
@@ -666,6 +820,12 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
         ak_level* p = &S->lv[i - 1];
         const dim3 g = grid(e->rows, e->cols);
         const size_t bytes = (size_t)e->rows * e->cols * 4;
+        if (e->rows * e->cols <= AK_SMALL_PX && e->rows >= 2 && e->cols >= 2) {
+            hipLaunchKernelGGL(ak_level_small_kernel, dim3(1), dim3(1024), (size_t)2 * e->rows * e->cols * 4, st, p->Lt, p->cols,
+                               e->octave > p->octave ? 1 : 0, e->rows, e->cols, g5, S->kc, e->octave, e->nsteps,
+                               S->tau_dev + (size_t)i * AK_MAX_STEPS, e->Lt, e->Lsmooth);
+            continue;
+        }
         // the level's starting image: the previous level's final Lt (halved at a new octave); it lands in tmpA or e->Lt
         // so that the ping-pong of the FED steps ends in e->Lt
         float* cur = (e->nsteps & 1) ? S->tmpA : e->Lt;
@@ -700,6 +860,12 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
                                e->cols, e->border, (float)P->threshold, i, S->n_cand, S->cand, S->cand_cap);
     }
     HIP_TRY(ctx, hipGetLastError());
+    static const bool timing = getenv("IMATCH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_enq = now();
     // candidates -> host
     int n_cand = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&n_cand, S->n_cand, 4, hipMemcpyDeviceToHost, st));
@@ -707,67 +873,77 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     if (n_cand > S->cand_cap)
         return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: %d candidates exceed the list of %d", n_cand, S->cand_cap);
     std::vector<float> raw((size_t)n_cand * AK_CAND_FLOATS);
+    const auto t_gpu = now();
     if (n_cand) HIP_TRY(ctx, hipMemcpy(raw.data(), S->cand, raw.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<ak_cand> c((size_t)n_cand);
-    for (int i = 0; i < n_cand; ++i) {
-        const float* r = raw.data() + (size_t)i * AK_CAND_FLOATS;
-        c[i].level = (int)r[0]; c[i].x = (int)r[1]; c[i].y = (int)r[2];
-        memcpy(c[i].v, r + 3, 36);
-        c[i].alive = false;
-    }
-    std::sort(c.begin(), c.end(), [](const ak_cand& a, const ak_cand& b) {
-        return a.level != b.level ? a.level < b.level : (a.y != b.y ? a.y < b.y : a.x < b.x);
-    });
-    std::vector<std::vector<int>> pts((size_t)S->n_levels);
-    for (int i = 0; i < n_cand; ++i) pts[c[i].level].push_back(i);
-    // same level: row-major scan, the first kept neighbour decides
-    for (int i = 0; i < n_cand; ++i) {
-        const int r = S->lv[c[i].level].sigma_size;
-        const int nb = find_neighbor(c, pts[c[i].level], c[i].x, c[i].y, r);
-        if (nb >= 0) {
-            if (c[i].v[4] > c[nb].v[4]) c[nb].alive = false;
-            else continue;
+    const auto t_dl = now();
+    std::vector<ak_level_pts> LP;
+    bucket_candidates(raw.data(), n_cand, S, LP);
+    // same level: row-major scan, the first kept neighbour decides (levels are independent of one another here)
+    imatch_parallel_for(ctx, S->n_levels, [&](int l) {
+        ak_level_pts& P = LP[l];
+        const int r = S->lv[l].sigma_size;
+        for (int p = 0; p < (int)P.x.size(); ++p) {
+            const int nb = P.find(P.x[p], P.y[p], r);
+            if (nb >= 0) {
+                if (P.v[(size_t)p * 9 + 4] > P.v[(size_t)nb * 9 + 4]) P.alive[nb] = 0;
+                else continue;
+            }
+            P.alive[p] = 1;
         }
-        c[i].alive = true;
-    }
-    for (int l = 1; l < S->n_levels; ++l) {   // against the level below
+    });
+    // Against the level below, then against the level above. OpenCV runs the level pairs one after the other, but pair
+    // (l, l-1) only READS level l's flags as the phase before left them (the pass that changes them comes later) and is
+    // the only one that WRITES level l-1's: with a snapshot of the flags per phase the pairs are independent.
+    std::vector<std::vector<uint8_t>> snap((size_t)S->n_levels);
+    for (int l = 0; l < S->n_levels; ++l) snap[l] = LP[l].alive;
+    imatch_parallel_for(ctx, S->n_levels - 1, [&](int i) {
+        const int l = i + 1;
         const int dr = (int)S->lv[l].ratio / (int)S->lv[l - 1].ratio, r = S->lv[l].sigma_size;
-        for (int id : pts[l])
-            if (c[id].alive) {
-                const int nb = find_neighbor(c, pts[l - 1], c[id].x * dr, c[id].y * dr, r);
-                if (nb >= 0 && c[id].v[4] > c[nb].v[4]) c[nb].alive = false;
+        const ak_level_pts& P = LP[l];
+        ak_level_pts& Q = LP[l - 1];
+        for (int p = 0; p < (int)P.x.size(); ++p)
+            if (snap[l][p]) {
+                const int nb = Q.find(P.x[p] * dr, P.y[p] * dr, r);
+                if (nb >= 0 && P.v[(size_t)p * 9 + 4] > Q.v[(size_t)nb * 9 + 4]) Q.alive[nb] = 0;
             }
-    }
-    for (int l = S->n_levels - 2; l >= 0; --l) {   // against the level above
+    });
+    for (int l = 0; l < S->n_levels; ++l) snap[l] = LP[l].alive;
+    imatch_parallel_for(ctx, S->n_levels - 1, [&](int l) {
         const int dr = (int)S->lv[l + 1].ratio / (int)S->lv[l].ratio, r = S->lv[l].sigma_size;
-        for (int id : pts[l])
-            if (c[id].alive) {
-                const int nb = find_neighbor(c, pts[l + 1], c[id].x / dr, c[id].y / dr, r);
-                if (nb >= 0 && c[id].v[4] > c[nb].v[4]) c[nb].alive = false;
+        const ak_level_pts& P = LP[l];
+        ak_level_pts& Q = LP[l + 1];
+        for (int p = 0; p < (int)P.x.size(); ++p)
+            if (snap[l][p]) {
+                const int nb = Q.find(P.x[p] / dr, P.y[p] / dr, r);
+                if (nb >= 0 && P.v[(size_t)p * 9 + 4] > Q.v[(size_t)nb * 9 + 4]) Q.alive[nb] = 0;
             }
-    }
+    });
     // A5
     S->kp.clear();
     std::vector<float> kdev;
-    for (int i = 0; i < n_cand; ++i) {
-        if (!c[i].alive) continue;
-        const ak_level* e = &S->lv[c[i].level];
-        const float* v = c[i].v;   // 0 1 2 / 3 4 5 / 6 7 8 = rows y-1, y, y+1
-        const float Dx = 0.5f * (v[5] - v[3]), Dy = 0.5f * (v[7] - v[1]);
-        const float Dxx = v[5] + v[3] - 2.0f * v[4], Dyy = v[7] + v[1] - 2.0f * v[4];
-        const float Dxy = 0.25f * (v[8] + v[0] - v[2] - v[6]);
-        float dx = 0.f, dy = 0.f;
-        double det = (double)Dxx * Dyy - (double)Dxy * Dxy;
-        if (det != 0) {
-            det = 1. / det;
-            dx = (float)(((double)(-Dx) * Dyy - (double)(-Dy) * Dxy) * det);
-            dy = (float)(((double)(-Dy) * Dxx - (double)(-Dx) * Dxy) * det);
+    for (int l = 0; l < S->n_levels; ++l) {
+        const ak_level* e = &S->lv[l];
+        const ak_level_pts& P = LP[l];
+        for (int p = 0; p < (int)P.x.size(); ++p) {
+            if (!P.alive[p]) continue;
+            const float* v = &P.v[(size_t)p * 9];   // 0 1 2 / 3 4 5 / 6 7 8 = rows y-1, y, y+1
+            const float Dx = 0.5f * (v[5] - v[3]), Dy = 0.5f * (v[7] - v[1]);
+            const float Dxx = v[5] + v[3] - 2.0f * v[4], Dyy = v[7] + v[1] - 2.0f * v[4];
+            const float Dxy = 0.25f * (v[8] + v[0] - v[2] - v[6]);
+            float dx = 0.f, dy = 0.f;
+            double det = (double)Dxx * Dyy - (double)Dxy * Dxy;
+            if (det != 0) {
+                det = 1. / det;
+                dx = (float)(((double)(-Dx) * Dyy - (double)(-Dy) * Dxy) * det);
+                dy = (float)(((double)(-Dy) * Dxx - (double)(-Dx) * Dxy) * det);
+            }
+            if (fabsf(dx) > 1.0f || fabsf(dy) > 1.0f) continue;
+            const float rec[8] = {(P.x[p] + dx) * e->ratio + .5f * (e->ratio - 1.0f), (P.y[p] + dy) * e->ratio + .5f * (e->ratio - 1.0f),
+                                  2.0f * (e->esigma * 1.5f), 0.f, v[4], (float)e->octave, (float)l, 0.f};
+            kdev.insert(kdev.end(), rec, rec + 8);
         }
-        if (fabsf(dx) > 1.0f || fabsf(dy) > 1.0f) continue;
-        const float rec[8] = {(c[i].x + dx) * e->ratio + .5f * (e->ratio - 1.0f), (c[i].y + dy) * e->ratio + .5f * (e->ratio - 1.0f),
-                              2.0f * (e->esigma * 1.5f), 0.f, v[4], (float)e->octave, (float)c[i].level, 0.f};
-        kdev.insert(kdev.end(), rec, rec + 8);
     }
+    const auto t_filter = now();
     const int n = (int)(kdev.size() / 8);
     S->n_kp = n;
     S->kp.assign((size_t)n * 7, 0.f);
@@ -790,6 +966,10 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     HIP_TRY(ctx, hipMemcpyAsync(S->desc.data(), S->desc_dev, (size_t)n * 64 * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     for (int i = 0; i < n; ++i) memcpy(S->kp.data() + (size_t)i * 7, kdev.data() + (size_t)i * 8, 28);
+    if (timing)
+        fprintf(stderr, "[imatch] akaze host phases: wait for GPU %.3f ms, candidates down %.3f ms (%d), filter + sub-pixel %.3f ms, "
+                "orientation + descriptors + download %.3f ms (%d)\n", ms(t_enq, t_gpu), ms(t_gpu, t_dl), n_cand, ms(t_dl, t_filter),
+                ms(t_filter, now()), n);
     return IMATCH_OK;
 }
 
