@@ -6,7 +6,7 @@
 //   gauss_kernel<N>      N x N Gaussian, BORDER_REPLICATE (9 x 9 from the u8 image, 5 x 5 per level)
 //   flow_kernel          Scharr pair of Lsmooth -> conductivity g2 (or |grad| + its maximum, for the contrast factor)
 //   fed_kernel           one explicit diffusion step Lt' = Lt + tau/2 * div(g grad Lt)
-//   half_kernel          INTER_AREA by 2 at a new octave
+//   area_kernel          resize(INTER_AREA) at a new octave (2 x 2 boxes, or the general decimation table)
 //   deriv1_kernel        Lx, Ly of Lsmooth by the Scharr pair stretched to +- sigma_size
 //   det_kernel           Lxx, Lxy, Lyy from Lx, Ly -> Ldet
 //   candidates_kernel    strict 3 x 3 maxima above the threshold inside the level's border, with their 3 x 3 response
@@ -292,12 +292,59 @@ ak_fed_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, int ro
     }
 }
 
+// resize(INTER_AREA) of an f32 plane at a new octave: exact 2 x 2 boxes in ResizeAreaFast's vector order, otherwise the
+// decimation table of resize.cpp:computeResizeAreaTab recomputed per output pixel (as preproc.hip does for u8): a
+// fractional head, whole cells and a fractional tail per axis, row sums then beta-weighted rows in the table's order.
+struct ak_span {
+    int s_head, s1, s2, s_tail;
+    float a_head, a_mid, a_tail;
+};
+
+__device__ __forceinline__ ak_span ak_area_entry(int d, double scale, int ssize) {
+    ak_span e;
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, ssize - f1);
+    int sx1 = (int)ceil(f1), sx2 = (int)floor(f2);
+    sx2 = min(sx2, ssize - 1);
+    sx1 = min(sx1, sx2);
+    e.s_head = e.s_tail = -1;
+    e.a_head = e.a_tail = 0.f;
+    if (sx1 - f1 > 1e-3) { e.s_head = sx1 - 1; e.a_head = (float)((sx1 - f1) / cell); }
+    e.s1 = sx1; e.s2 = sx2;
+    e.a_mid = (float)(1.0 / cell);
+    if (f2 - sx2 > 1e-3) { e.s_tail = sx2; e.a_tail = (float)(fmin(fmin(f2 - sx2, 1.), cell) / cell); }
+    return e;
+}
+
+__device__ __forceinline__ float ak_area_row(const float* __restrict__ S, const ak_span& ex) {
+    float buf = 0.f;
+    if (ex.s_head >= 0) buf += S[ex.s_head] * ex.a_head;
+    for (int sx = ex.s1; sx < ex.s2; ++sx) buf += S[sx] * ex.a_mid;
+    if (ex.s_tail >= 0) buf += S[ex.s_tail] * ex.a_tail;
+    return buf;
+}
+
+// fast != 0: srows == 2 rows and scols == 2 cols exactly
+__device__ __forceinline__ float ak_area_pixel(const float* __restrict__ src, int srows, int scols, int x, int y, int fast,
+                                               double scale_x, double scale_y) {
+    if (fast) {
+        const float* s = src + (size_t)(2 * y) * scols + 2 * x;
+        return ((s[0] + s[1]) + (s[scols] + s[scols + 1])) * 0.25f;
+    }
+    const ak_span ex = ak_area_entry(x, scale_x, scols), ey = ak_area_entry(y, scale_y, srows);
+    float sum = 0.f;
+    if (ey.s_head >= 0) sum += ey.a_head * ak_area_row(src + (size_t)ey.s_head * scols, ex);
+    for (int sy = ey.s1; sy < ey.s2; ++sy) sum += ey.a_mid * ak_area_row(src + (size_t)sy * scols, ex);
+    if (ey.s_tail >= 0) sum += ey.a_tail * ak_area_row(src + (size_t)ey.s_tail * scols, ex);
+    return sum;
+}
+
 __global__ void __launch_bounds__(256)
-ak_half_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst, int rows, int cols) {
+ak_area_kernel(const float* __restrict__ src, int srows, int scols, float* __restrict__ dst, int rows, int cols, int fast,
+               double scale_x, double scale_y) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
-    const float* s = src + (size_t)(2 * y) * scols + 2 * x;
-    dst[(size_t)y * cols + x] = ((s[0] + s[1]) + (s[scols] + s[scols + 1])) * 0.25f;
+    dst[(size_t)y * cols + x] = ak_area_pixel(src, srows, scols, x, y, fast, scale_x, scale_y);
 }
 
 // One whole evolution level of a SMALL plane (rows * cols <= AK_SMALL_PX: 120 x 160 and below, i.e. octaves 2 and 3 of a
@@ -307,7 +354,8 @@ ak_half_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst
 #define AK_SMALL_PX 19200
 #define AK_SMALL_PT 19      // pixels per thread at 1024 threads
 __global__ void __launch_bounds__(1024)
-ak_level_small_kernel(const float* __restrict__ prev, int pcols, int halve, int rows, int cols, ak_taps g5,
+ak_level_small_kernel(const float* __restrict__ prev, int prows, int pcols, int halve, int fast, double scale_x, double scale_y,
+                      int rows, int cols, ak_taps g5,
                       const float* __restrict__ kc, int octave, int nsteps, const float* __restrict__ tau,
                       float* __restrict__ Lt, float* __restrict__ Lsmooth) {
     extern __shared__ float ak_lds[];
@@ -318,8 +366,7 @@ ak_level_small_kernel(const float* __restrict__ prev, int pcols, int halve, int 
     for (int p = tid; p < px; p += 1024) {
         const int y = p / cols, x = p - y * cols;
         if (halve) {
-            const float* s = prev + (size_t)(2 * y) * pcols + 2 * x;
-            A[p] = ((s[0] + s[1]) + (s[pcols] + s[pcols + 1])) * 0.25f;
+            A[p] = ak_area_pixel(prev, prows, pcols, x, y, fast, scale_x, scale_y);
         } else {
             A[p] = prev[p];
         }
@@ -652,11 +699,6 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
         const float rfactor = 1.0f / power;
         const int lh = (int)(h * rfactor), lw = (int)(w * rfactor);
         if ((lw < 80 || lh < 40) && i != 0) break;
-        if (i > 0 && (S->lv[S->n_levels - 1].rows != 2 * lh || S->lv[S->n_levels - 1].cols != 2 * lw)) {
-            imatch_akaze_state_free(ctx);
-            return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: %dx%d does not halve exactly at octave %d (general INTER_AREA "
-                                  "for f32 planes is not implemented)", w, h, i);
-        }
         for (int j = 0; j < nsub; ++j) {
             ak_level* e = &S->lv[S->n_levels++];
             e->rows = lh; e->cols = lw;
@@ -820,9 +862,12 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
         ak_level* p = &S->lv[i - 1];
         const dim3 g = grid(e->rows, e->cols);
         const size_t bytes = (size_t)e->rows * e->cols * 4;
+        // resize(): scale = 1 / (dsize / ssize) per axis; the 2 x 2 box path when both are exactly 2
+        const double sc_x = 1. / ((double)e->cols / p->cols), sc_y = 1. / ((double)e->rows / p->rows);
+        const int fast = fabs(sc_x - 2.0) < 2.220446049250313e-16 && fabs(sc_y - 2.0) < 2.220446049250313e-16;
         if (e->rows * e->cols <= AK_SMALL_PX && e->rows >= 2 && e->cols >= 2) {
-            hipLaunchKernelGGL(ak_level_small_kernel, dim3(1), dim3(1024), (size_t)2 * e->rows * e->cols * 4, st, p->Lt, p->cols,
-                               e->octave > p->octave ? 1 : 0, e->rows, e->cols, g5, S->kc, e->octave, e->nsteps,
+            hipLaunchKernelGGL(ak_level_small_kernel, dim3(1), dim3(1024), (size_t)2 * e->rows * e->cols * 4, st, p->Lt, p->rows,
+                               p->cols, e->octave > p->octave ? 1 : 0, fast, sc_x, sc_y, e->rows, e->cols, g5, S->kc, e->octave, e->nsteps,
                                S->tau_dev + (size_t)i * AK_MAX_STEPS, e->Lt, e->Lsmooth);
             continue;
         }
@@ -831,8 +876,8 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
         float* cur = (e->nsteps & 1) ? S->tmpA : e->Lt;
         float* oth = (e->nsteps & 1) ? e->Lt : S->tmpA;
         if (e->octave > p->octave)
-            hipLaunchKernelGGL(ak_half_kernel, dim3((e->cols + 63) / 64, (e->rows + 3) / 4), dim3(256), 0, st, p->Lt, p->cols, cur,
-                               e->rows, e->cols);
+            hipLaunchKernelGGL(ak_area_kernel, dim3((e->cols + 63) / 64, (e->rows + 3) / 4), dim3(256), 0, st, p->Lt, p->rows,
+                               p->cols, cur, e->rows, e->cols, fast, sc_x, sc_y);
         else
             HIP_TRY(ctx, hipMemcpyAsync(cur, p->Lt, bytes, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL((ak_gauss_kernel<float>), g, dim3(256), 0, st, cur, e->rows, e->cols, g5, e->Lsmooth, (float*)nullptr);

@@ -164,8 +164,7 @@ typedef struct imatch_akaze_params {
 /* Replaces find_kp_dp's body as checked in (MF:199-221 with the AKAZE call of MF:210-211):
  * [CLAHE ->] cv2.AKAZE_create(descriptor_type=AKAZE_DESCRIPTOR_KAZE, threshold, nOctaves, nOctaveLayers,
  * diffusivity=KAZE_DIFF_PM_G2).detectAndCompute(img, None). The result stays with the context until the next
- * extraction: *n_out keypoints, fetched with imatch_akaze_download. The image's sides must halve exactly at every
- * octave (multiples of 2^(octaves-1)), else IMATCH_ESIZE. */
+ * extraction: *n_out keypoints, fetched with imatch_akaze_download. */
 int imatch_akaze_extract(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, const imatch_akaze_params* params,
                          int64_t* n_out);
 int imatch_akaze_extract_dev(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int stride,

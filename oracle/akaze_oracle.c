@@ -33,13 +33,14 @@
  *     Lx, Ly, Gaussian 2.5 scale weight per sample and 1.5 per subregion, (sum dx, sum dy, sum |dx|, sum |dy|), unit norm.
  * Where OpenCV's float order depends on its build (SIMD width, FMA) one order is fixed here: filters are ascending-tap
  * fmaf chains (as sift_oracle.c), everything else is the source's expression order without contraction. fastAtan2 and
- * OpenCV's exp are libm's here. Level sizes must halve exactly (W, H multiples of 2^(octaves-1)): the general
- * INTER_AREA path for f32 is not restated, such images are refused.
+ * OpenCV's exp are libm's here. A new octave is resize(INTER_AREA) of the last level (oracle_resize_area_f32).
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+int oracle_resize_area_f32(const float* src, int rows, int cols, float* dst, int drows, int dcols);
 
 #define AK_MAX_LEVELS 32
 #define AK_MAX_STEPS 256
@@ -375,7 +376,7 @@ void oracle_akaze_free(oracle_akaze* A) {
 }
 
 /* AKAZE_create(DESCRIPTOR_KAZE, 0, 3, threshold, omax, nsublevels, DIFF_PM_G2).detectAndCompute(image, None);
- * NULL when a level size does not halve exactly (see header) or the image is too small for one level. */
+ * NULL for bad arguments. */
 oracle_akaze* oracle_akaze_run(const uint8_t* image, int rows, int cols, double threshold, int omax, int nsublevels) {
     const float soffset = 1.6f, derivative_factor = 1.5f, smax = 12.0f * sqrtf(2.0f);
     if (rows < 3 || cols < 3 || omax < 1 || nsublevels < 1 || omax * nsublevels > AK_MAX_LEVELS) return NULL;
@@ -385,7 +386,6 @@ oracle_akaze* oracle_akaze_run(const uint8_t* image, int rows, int cols, double 
         const float rfactor = 1.0f / power;
         const int lh = (int)(rows * rfactor), lw = (int)(cols * rfactor);
         if ((lw < 80 || lh < 40) && i != 0) break;
-        if (i > 0 && (A->lv[A->n_levels - 1].rows != 2 * lh || A->lv[A->n_levels - 1].cols != 2 * lw)) { oracle_akaze_free(A); return NULL; }
         for (int j = 0; j < nsublevels; ++j) {
             ak_level* e = &A->lv[A->n_levels++];
             e->rows = lh; e->cols = lw;
@@ -427,12 +427,7 @@ oracle_akaze* oracle_akaze_run(const uint8_t* image, int rows, int cols, double 
             const ak_level* p = &A->lv[i - 1];
             const size_t px = (size_t)e->rows * e->cols;
             if (e->octave > p->octave) {
-                /* resize(INTER_AREA) by exactly 2, the vector path's order: ((a + b) + (c + d)) * 0.25 */
-                for (int y = 0; y < e->rows; ++y)
-                    for (int x = 0; x < e->cols; ++x) {
-                        const float* s = p->Lt + (size_t)(2 * y) * p->cols + 2 * x;
-                        e->Lt[(size_t)y * e->cols + x] = ((s[0] + s[1]) + (s[p->cols] + s[p->cols + 1])) * 0.25f;
-                    }
+                oracle_resize_area_f32(p->Lt, p->rows, p->cols, e->Lt, e->rows, e->cols);   /* sift_oracle.c */
                 kc *= 0.75f;
             } else {
                 memcpy(e->Lt, p->Lt, sizeof(float) * px);

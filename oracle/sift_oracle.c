@@ -204,6 +204,50 @@ int oracle_resize_area(const uint8_t* src, int rows, int cols, uint8_t* dst, int
     return 0;
 }
 
+/* resize(src, dst, dsize, 0, 0, INTER_AREA) for f32 planes, shrinking (the octave step of the AKAZE scale space,
+ * AKAZEFeatures.cpp create_nonlinear_scale_space): exact 2 x 2 boxes take ResizeAreaFast's vector order
+ * ((a + b) + (c + d)) * 0.25, everything else the decimation table above with f32 row sums and beta-weighted rows. */
+int oracle_resize_area_f32(const float* src, int rows, int cols, float* dst, int drows, int dcols) {
+    if (drows <= 0 || dcols <= 0 || drows > rows || dcols > cols) return -1;
+    const double sx = 1. / ((double)dcols / cols), sy = 1. / ((double)drows / rows);
+    const int isx = cv_round_d(sx), isy = cv_round_d(sy);
+    if (fabs(sx - isx) < DBL_EPSILON && fabs(sy - isy) < DBL_EPSILON && isx == 2 && isy == 2) {
+        for (int y = 0; y < drows; ++y)
+            for (int x = 0; x < dcols; ++x) {
+                const float* s = src + (size_t)(2 * y) * cols + 2 * x;
+                dst[(size_t)y * dcols + x] = ((s[0] + s[1]) + (s[cols] + s[cols + 1])) * 0.25f;
+            }
+        return 0;
+    }
+    dec_alpha* xtab = (dec_alpha*)malloc(sizeof(dec_alpha) * (size_t)cols * 2);
+    dec_alpha* ytab = (dec_alpha*)malloc(sizeof(dec_alpha) * (size_t)rows * 2);
+    const int nx = area_tab(cols, dcols, sx, xtab), ny = area_tab(rows, drows, sy, ytab);
+    float* buf = (float*)malloc(sizeof(float) * dcols);
+    float* sum = (float*)calloc(dcols, sizeof(float));
+    int prev_dy = ytab[0].di;
+    for (int j = 0; j < ny; ++j) {
+        const float beta = ytab[j].alpha;
+        const int dy = ytab[j].di;
+        const float* S = src + (size_t)ytab[j].si * cols;
+        for (int dx = 0; dx < dcols; ++dx) buf[dx] = 0.f;
+        for (int k = 0; k < nx; ++k) buf[xtab[k].di] += S[xtab[k].si] * xtab[k].alpha;
+        if (dy != prev_dy) {
+            float* D = dst + (size_t)prev_dy * dcols;
+            for (int dx = 0; dx < dcols; ++dx) {
+                D[dx] = sum[dx];
+                sum[dx] = beta * buf[dx];
+            }
+            prev_dy = dy;
+        } else {
+            for (int dx = 0; dx < dcols; ++dx) sum[dx] += beta * buf[dx];
+        }
+    }
+    float* D = dst + (size_t)prev_dy * dcols;
+    for (int dx = 0; dx < dcols; ++dx) D[dx] = sum[dx];
+    free(xtab); free(ytab); free(buf); free(sum);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Spec S: SIFT (sift.dispatch.cpp / sift.simd.hpp), reference call match_finder.py:205-209,220.
  * ---------------------------------------------------------------------------------------- */

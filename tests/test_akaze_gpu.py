@@ -45,7 +45,7 @@ def test_frame_640x480_all_planes(ctx):
 
 def test_other_sizes(ctx):
     m = synth.synth_map(1024, seed=9)
-    for h, w in ((240, 320), (88, 200), (360, 648), (1024, 1024)):
+    for h, w in ((240, 320), (88, 200), (360, 648), (321, 448), (479, 641), (250, 333), (1024, 1024)):   # odd sizes: general INTER_AREA
         _compare(ctx, np.ascontiguousarray(m[:h, :w]), planes=(h < 500))
 
 
@@ -54,7 +54,7 @@ def test_flat_and_tiny_images(ctx):
     assert kp.shape == (0, 7) and desc.shape == (0, 64)
     _compare(ctx, np.random.default_rng(1).integers(0, 256, (48, 64), dtype=np.uint8))   # one octave, no room inside the border
     with pytest.raises(ImatchError):
-        ctx.akaze_extract(np.zeros((321, 448), np.uint8))      # 321 does not halve exactly
+        ctx.akaze_extract(np.zeros((64, 64), np.uint8), AkazeParams(n_octaves=0))
 
 
 def test_clahe_first_as_find_kp_dp(ctx):
