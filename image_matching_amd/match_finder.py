@@ -23,7 +23,7 @@ from . import draw
 from ._lib import AkazeParams, SiftParams
 from .cvtypes import DeviceDescriptors, GoodMatches, KeyPoints
 from .geodetic_conv import GeodeticConvert
-from .params import get_param
+from .params import get_param, get_param_or_default
 from .utils import default_context, isConvex, line_intersection, resize_img
 
 
@@ -47,9 +47,11 @@ def _features_of(ctx, dp):
 
 
 class match_finder():
-    def __init__(self, ctx=None, detector="sift"):
+    def __init__(self, ctx=None, detector=None):
         # "sift": the detector north_star names (the commented call of match_finder.py:205-209); "akaze": the call the
         # checked-in file makes (match_finder.py:210-211). Everything downstream is the same code.
+        if detector is None:
+            detector = get_param_or_default("detector")
         if detector not in ("sift", "akaze"):
             raise ValueError("detector must be 'sift' or 'akaze'")
         self.detector = detector

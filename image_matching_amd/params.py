@@ -16,6 +16,9 @@ DEFAULTS = {
     "low_scale_restriction_homography": 0.5,
     "high_scale_restriction_homography": 2.0,
     "camera_pitch_angle": 0.0,
+    # not a parameter of the reference: "sift" (the detector north_star names, the commented call of
+    # match_finder.py:205-209) or "akaze" (the call the checked-in file makes, match_finder.py:210-211)
+    "detector": "sift",
 }
 
 _table = dict(DEFAULTS)
@@ -41,3 +44,11 @@ def get_param(name):
         if name not in _table:
             raise
     return _table[name]
+
+
+def get_param_or_default(name):
+    """For keys the reference does not have (a flight YAML will not hold them)."""
+    try:
+        return get_param(name)
+    except Exception:
+        return DEFAULTS[name]
