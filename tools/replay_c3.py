@@ -21,7 +21,7 @@ lowpass = float(sys.argv[3]) if len(sys.argv) > 3 else 1e6
 map_px, frame_px = 0.5, 0.375
 m = synth.synth_map(side, seed=1234)
 flight = synth.synth_flight(m, n, map_pixel_size=map_px, frame_pixel_size=frame_px, seed=1)
-mf = match_finder()
+mf = match_finder(detector=os.environ.get("REPLAY_DETECTOR", "sift"))   # "akaze": the detector the checked-in file runs
 mf.draw_matches = False          # the drawMatchesKnn canvas is only published on request (position_finder.py:319-320)
 main_map = replay.make_map(m, map_px)
 poi = replay.DEFAULT_CONFIG["camera_poi"] / 180.0 * np.pi
@@ -65,7 +65,7 @@ if os.environ.get("REPLAY_PROFILE"):
     pr.disable()
     pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
 print(json.dumps({
-    "metric": "frames/sec, position_finder loop (configs[2])", "value": n / wall, "unit": "frames/s", "n_gpus": 1,
+    "metric": "frames/sec, position_finder loop (configs[2])", "detector": mf.detector, "value": n / wall, "unit": "frames/s", "n_gpus": 1,
     "frames": n, "frame": "1280x720 u8", "map": "%dx%d synthetic, %.2f m/px" % (side, side, map_px),
     "ms_per_frame": wall / n * 1e3, "fixes": len(pf.fixes), "fix_rate": len(pf.fixes) / n,
     "position_error_m": {"median": float(np.median(err)) if err else None, "p90": float(np.percentile(err, 90)) if err else None,
