@@ -48,31 +48,41 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(frame, map_desc_sample, n_map, map_xy_sample, ratio, threads):
-    """The same chain through the CPU oracle on this box's host cores. The kNN leg runs against a bounded
-    slice of the map and is scaled linearly to the full descriptor count (it is a dense scan)."""
+def cpu_baseline(frames, map_desc_sample, n_map, map_xy_sample, ratio, threads):
+    """The same chain through the CPU oracle on this box's host cores, frame after frame for about two seconds of wall
+    time (`threads` OpenMP threads: tens of core-seconds). The kNN leg runs against the whole map when it holds at most
+    300 000 descriptors, else against a slice and is scaled linearly (it is a dense scan)."""
     import oracle
     oracle.lib()
-    t0 = time.perf_counter()
-    res = oracle.sift(oracle.clahe(frame))
-    t_ext = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    idx, dist = oracle.knn2(res.desc.astype(np.uint8), map_desc_sample, threads=threads)
-    t_knn_s = time.perf_counter() - t0
-    gq, gt, _ = oracle.ratio(idx, dist, ratio)
-    t0 = time.perf_counter()
-    if len(gq) >= 4:
-        oracle.homography(res.kp[gq, :2], map_xy_sample[gt], 0.1, seed=0)
-    t_h = time.perf_counter() - t0
-    t_knn = t_knn_s * n_map / max(len(map_desc_sample), 1)
-    total = t_ext + t_knn + t_h
+    oracle.sift(oracle.clahe(frames[0]))          # first touch: page in the library, spin up the OpenMP pool
+    t_ext = t_knn_s = t_h = 0.0
+    pairs = 0
+    done = 0
+    t_start = time.perf_counter()
+    for frame in frames:
+        t0 = time.perf_counter()
+        res = oracle.sift(oracle.clahe(frame))
+        t1 = time.perf_counter()
+        idx, dist = oracle.knn2(res.desc.astype(np.uint8), map_desc_sample, threads=threads)
+        t2 = time.perf_counter()
+        gq, gt, _ = oracle.ratio(idx, dist, ratio)
+        if len(gq) >= 4:
+            oracle.homography(res.kp[gq, :2], map_xy_sample[gt], 0.1, seed=0)
+        t3 = time.perf_counter()
+        t_ext += t1 - t0; t_knn_s += t2 - t1; t_h += t3 - t2
+        pairs += len(res.desc) * len(map_desc_sample)
+        done += 1
+        if time.perf_counter() - t_start > 2.0:
+            break
+    scale = n_map / max(len(map_desc_sample), 1)
+    total = t_ext + t_knn_s * scale + t_h
     return {
-        "value": 1.0 / total, "unit": "frames/s", "cores": threads, "kind": "port",
-        "sample": "1 frame 640x480: extract %.3fs (OpenMP) + kNN %d x %d measured %.2fs, scaled x%.1f to %d map "
-                  "descriptors + homography %.4fs; restatement of OpenCV, not OpenCV"
-                  % (t_ext, len(res.desc), len(map_desc_sample), t_knn_s, n_map / max(len(map_desc_sample), 1),
-                     n_map, t_h),
-        "knn_gdist_per_s": len(res.desc) * len(map_desc_sample) / t_knn_s / 1e9,
+        "value": done / total, "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": "%d frames 640x480, %.1f s of wall time on %d threads: extract %.3f s/frame (OpenMP) + kNN vs %d map "
+                  "descriptors %.3f s/frame%s + ratio and homography %.4f s/frame; restatement of OpenCV, not OpenCV"
+                  % (done, t_ext + t_knn_s + t_h, threads, t_ext / done, len(map_desc_sample), t_knn_s / done,
+                     "" if scale == 1 else " (scaled x%.1f to %d)" % (scale, n_map), t_h / done),
+        "knn_gdist_per_s": pairs / t_knn_s / 1e9,
     }
 
 
@@ -395,9 +405,9 @@ def main():
                                            "the timed region; not part of value"}
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
-            n_s = min(n_map, 100_000)
+            n_s = n_map if n_map <= 300_000 else 100_000
             d_s = f_local.download(keypoints=False)[1][:n_s].astype(np.uint8)
-            out["cpu_baseline"] = cpu_baseline(frames_h[0], d_s, n_map, map_xy[:n_s], ratio, threads)
+            out["cpu_baseline"] = cpu_baseline(frames_h[:16], d_s, n_map, map_xy[:n_s], ratio, threads)
         else:
             out["cpu_baseline"] = None
     else:
