@@ -310,7 +310,7 @@ template <int QB, int TN, int XM>   // QB blocks of 16 queries per wave (8: 128 
 __global__ void __launch_bounds__(256, 2)
 knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ thneg,
               int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi,
-              int* __restrict__ gthr) {
+              int* __restrict__ gthr, int young, unsigned young_wg) {
     static_assert(QB % 4 == 0, "thresholds are fetched 64 queries at a time");
     constexpr int STAGE_U4 = TN * 16 + TN / 4;
     constexpr int NT = TN / 16;                  // 16-row tiles per stage
@@ -374,7 +374,9 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int age = s - s_begin;
-        const bool exchange = age < 8 || (age & XM) == 0;   // XM + 1 stages between bound exchanges
+        // every stage while the chunk is young -- only workgroups of the first rounds start from loose bounds, later ones
+        // inherit the chip-wide words -- then XM + 1 stages between bound exchanges
+        const bool exchange = (age < young && blockIdx.x < young_wg) || (age & XM) == 0;
         if (exchange) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
@@ -728,6 +730,8 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     static const int mfma16 = getenv("IMATCH_KNN_MFMA16") ? atoi(getenv("IMATCH_KNN_MFMA16")) : 1;
     static const int tn_env = getenv("IMATCH_KNN_TN") ? atoi(getenv("IMATCH_KNN_TN")) : 128;
     static const int xmask = getenv("IMATCH_KNN_XMASK") ? atoi(getenv("IMATCH_KNN_XMASK")) : 7;
+    static const int young = getenv("IMATCH_KNN_YOUNG") ? atoi(getenv("IMATCH_KNN_YOUNG")) : 8;
+    static const unsigned young_wg = getenv("IMATCH_KNN_YOUNG_WG") ? (unsigned)atoi(getenv("IMATCH_KNN_YOUNG_WG")) : 0xffffffffu;
     const bool use16 = mfma16 && QB == 4;
     const int TNs = (use16 && tn_env == 128 && t->n_pad % 128 == 0) ? 128 : 64;
     const int qtile = 4 * 32 * QB;
@@ -758,7 +762,7 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     if (use16) {
         const unsigned grid = (unsigned)(nQt * nChunks);
 #define LAUNCH16(TN_, XM_) hipLaunchKernelGGL((knn2_kernel16<8, TN_, XM_>), dim3(grid), dim3(256), 0, ctx->stream, \
-        (const uint4*)q->desc, (const uint4*)t->desc, t->hneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr)
+        (const uint4*)q->desc, (const uint4*)t->desc, t->hneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr, young, young_wg)
         if (TNs == 128 && xmask == 3) LAUNCH16(128, 3);
         else if (TNs == 128) LAUNCH16(128, 7);
         else LAUNCH16(64, 3);
