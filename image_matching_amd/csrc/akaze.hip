@@ -349,9 +349,10 @@ ak_area_kernel(const float* __restrict__ src, int srows, int scols, float* __res
 
 // One whole evolution level of a SMALL plane (rows * cols <= AK_SMALL_PX: 120 x 160 and below, i.e. octaves 2 and 3 of a
 // 640 x 480 frame, which hold 139 of the 192 diffusion steps) in ONE workgroup: the level's image and its conductivity
-// stay in LDS (2 x 75 KB) across the start (copy or halving), the 5 x 5 Gaussian, the Scharr pair and every FED step.
+// stay in LDS (2 x 76 KB) across the start (copy or halving), the 5 x 5 Gaussian, the Scharr pair and every FED step.
 // Replaces 3 + nsteps launches of a few microseconds of work each; same expressions, so the planes are unchanged.
 #define AK_SMALL_PX 19200
+#define AK_SMALL_LDS_FLOATS 40000   // 2 px + 4 cols must fit: 160 000 bytes of the CU's 160 KB
 #define AK_SMALL_PT 19      // pixels per thread at 1024 threads
 __global__ void __launch_bounds__(1024)
 ak_level_small_kernel(const float* __restrict__ prev, int prows, int pcols, int halve, int fast, double scale_x, double scale_y,
@@ -360,9 +361,14 @@ ak_level_small_kernel(const float* __restrict__ prev, int prows, int pcols, int 
                       float* __restrict__ Lt, float* __restrict__ Lsmooth) {
     extern __shared__ float ak_lds[];
     const int px = rows * cols;
-    float* A = ak_lds;
-    float* F = ak_lds + px;
+    // two planes, each with a guard row of `cols` zeros before and after it, so that the step below can read all four
+    // neighbours of any pixel without clamping (a dropped neighbour has a zero coefficient)
+    float* A = ak_lds + cols;
+    float* F = ak_lds + px + 3 * cols;
     const int tid = threadIdx.x;
+    for (int i = tid; i < cols; i += 1024) {
+        ak_lds[i] = 0.f; ak_lds[px + cols + i] = 0.f; ak_lds[px + 2 * cols + i] = 0.f; ak_lds[2 * px + 3 * cols + i] = 0.f;
+    }
     for (int p = tid; p < px; p += 1024) {
         const int y = p / cols, x = p - y * cols;
         if (halve) {
@@ -405,51 +411,87 @@ ak_level_small_kernel(const float* __restrict__ prev, int prows, int pcols, int 
         }
     }
     __syncthreads();
+    // The conductivity does not change during the cycle: each thread keeps the four sums (g_c + g_n) of its pixels in
+    // registers (0 where OpenCV's edge rules drop the neighbour, all four 0 at the corners: the dropped terms are then
+    // exact zeros at the places the source leaves them out) and F's LDS becomes the second image plane, so a step is
+    // five LDS reads per pixel and one barrier.
+    float cR[AK_SMALL_PT], cL[AK_SMALL_PT], cD[AK_SMALL_PT], cU[AK_SMALL_PT];
+    {
+        // (y, x) of pixel tid + 1024 j by stepping: 1024 = qs * cols + rs
+        const int qs = 1024 / cols, rs = 1024 - qs * cols;
+        int y = tid / cols, x = tid - y * cols;
+#pragma unroll
+        for (int j = 0; j < AK_SMALL_PT; ++j) {
+            const int p = tid + j * 1024;
+            const int pc = min(p, px - 1);   // threads beyond the plane compute on its last pixel and never store
+            const bool x0 = x == 0, x1 = x == cols - 1, y0 = y == 0, y1 = y == rows - 1;
+            const bool corner = (x0 || x1) && (y0 || y1);
+            const float fc = F[pc];
+            // F has guard rows too: the loads need no conditions, the selects drop what OpenCV's edge rules drop
+            const float r = fc + F[pc + 1], l = fc + F[pc - 1], d = fc + F[pc + cols], u = fc + F[pc - cols];
+            cR[j] = (x1 || corner) ? 0.f : r;
+            cL[j] = (x0 || corner) ? 0.f : l;
+            cD[j] = (y1 || corner) ? 0.f : d;
+            cU[j] = (y0 || corner) ? 0.f : u;
+            x += rs; y += qs;
+            if (x >= cols) { x -= cols; ++y; }
+            asm volatile("" ::: "memory");   // one pixel's operands in flight at a time: 76 registers hold the sums
+        }
+    }
+    __syncthreads();
+    float* B = F;
     for (int st = 0; st < nsteps; ++st) {
         const float step = tau[st] * 0.5f;
-        float nv[AK_SMALL_PT];
 #pragma unroll
         for (int j = 0; j < AK_SMALL_PT; ++j) {
             const int p = tid + j * 1024;
-            if (p >= px) break;
-            const int y = p / cols, x = p - y * cols;
-            const bool ex = x == 0 || x == cols - 1, ey = y == 0 || y == rows - 1;
-            const float tc = A[p], fc = F[p];
-            float sum;
-            if (ex && ey) {
-                sum = 0.f;
-            } else if (!ex && !ey) {
-                sum = (fc + F[p + 1]) * (A[p + 1] - tc) + (fc + F[p - 1]) * (A[p - 1] - tc) +
-                      (fc + F[p + cols]) * (A[p + cols] - tc) + (fc + F[p - cols]) * (A[p - cols] - tc);
-            } else if (ey) {
-                const int pv = y == 0 ? p + cols : p - cols;
-                sum = (fc + F[p + 1]) * (A[p + 1] - tc) + (fc + F[p - 1]) * (A[p - 1] - tc) + (fc + F[pv]) * (A[pv] - tc);
-            } else {
-                const int pn = x == 0 ? p + 1 : p - 1;
-                sum = (fc + F[pn]) * (A[pn] - tc) + (fc + F[p + cols]) * (A[p + cols] - tc) + (fc + F[p - cols]) * (A[p - cols] - tc);
+            if (p < px) {
+                // a dropped neighbour has a zero coefficient: whatever finite value sits there stands in for it
+                const float tc = A[p];
+                const float tr = A[p + 1], tl = A[p - 1], td = A[p + cols], tu = A[p - cols];
+                const float sum = cR[j] * (tr - tc) + cL[j] * (tl - tc) + cD[j] * (td - tc) + cU[j] * (tu - tc);
+                const float stepv = sum * step;
+                B[p] = tc + stepv;
             }
-            const float stepv = sum * step;
-            nv[j] = tc + stepv;
         }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < AK_SMALL_PT; ++j) {
-            const int p = tid + j * 1024;
-            if (p < px) A[p] = nv[j];
-        }
-        __syncthreads();
+        float* t_ = A; A = B; B = t_;
     }
     for (int p = tid; p < px; p += 1024) Lt[p] = A[p];
 }
 
-// Lx = D_x(src), Ly = D_y(src) with the pair stretched to +- s (sepFilter2D, BORDER_REFLECT_101)
+// The detector response of ALL levels in three launches (blockIdx.z = level; blocks beyond a level's tiles leave): the
+// levels are independent here, and a launch per level and stage was 60 dependent launches of a few microseconds.
+struct ak_levels_all {
+    int n;
+    int rows[AK_MAX_LEVELS], cols[AK_MAX_LEVELS], s[AK_MAX_LEVELS], border[AK_MAX_LEVELS];
+    const float* Lsmooth[AK_MAX_LEVELS];
+    float* Lx[AK_MAX_LEVELS];
+    float* Ly[AK_MAX_LEVELS];
+    float* Ldet[AK_MAX_LEVELS];
+};
+
+// the Scharr pair stretched to +- s (compute_derivative_kernels): [-1 0 1] and [n, w n, n], n = 1 / (2 s (w + 2)), w = 10/3
+__device__ __forceinline__ void ak_deriv_taps(int s, ak_taps& kd, ak_taps& ks) {
+    const float w = 10.0f / 3.0f, norm = 1.0f / (2.0f * s * (w + 2.0f));
+    kd.n = 2; kd.off[0] = -s; kd.off[1] = s; kd.k[0] = -1.f; kd.k[1] = 1.f;
+    ks.n = 3; ks.off[0] = -s; ks.off[1] = 0; ks.off[2] = s; ks.k[0] = norm; ks.k[1] = w * norm; ks.k[2] = norm;
+}
+
+// Lx = D_x(Lsmooth), Ly = D_y(Lsmooth) (sepFilter2D, BORDER_REFLECT_101)
 __global__ void __launch_bounds__(256)
-ak_deriv1_kernel(const float* __restrict__ src, int rows, int cols, int s, ak_taps kd, ak_taps ks, float* __restrict__ Lx,
-                 float* __restrict__ Ly) {
+ak_deriv1_kernel(ak_levels_all L) {
     __shared__ float in[AK_IN_H][AK_IN_W];
     __shared__ float tmp[AK_IN_H][AK_TW + 1];
+    const int lv = blockIdx.z;
+    const int rows = L.rows[lv], cols = L.cols[lv], s = L.s[lv];
     const int x0 = blockIdx.x * AK_TW, y0 = blockIdx.y * AK_TH;
-    ak_load_tile(src, rows, cols, x0, y0, s, 1, in);
+    if (x0 >= cols || y0 >= rows) return;
+    ak_taps kd, ks;
+    ak_deriv_taps(s, kd, ks);
+    float* __restrict__ Lx = L.Lx[lv];
+    float* __restrict__ Ly = L.Ly[lv];
+    ak_load_tile(L.Lsmooth[lv], rows, cols, x0, y0, s, 1, in);
     __syncthreads();
     const int x = threadIdx.x & 63;
     const bool live = x0 + x < cols;
@@ -468,14 +510,18 @@ ak_deriv1_kernel(const float* __restrict__ src, int rows, int cols, int s, ak_ta
 
 // Ldet = (D_x(Lx) D_y(Ly) - D_y(Lx)^2) s^4
 __global__ void __launch_bounds__(256)
-ak_det_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int rows, int cols, int s, ak_taps kd, ak_taps ks,
-              float* __restrict__ Ldet) {
+ak_det_kernel(ak_levels_all L) {
     __shared__ float in[AK_IN_H][AK_IN_W];
     __shared__ float tmp[AK_IN_H][AK_TW + 1];
+    const int lv = blockIdx.z;
+    const int rows = L.rows[lv], cols = L.cols[lv], s = L.s[lv];
     const int x0 = blockIdx.x * AK_TW, y0 = blockIdx.y * AK_TH;
+    if (x0 >= cols || y0 >= rows) return;
+    ak_taps kd, ks;
+    ak_deriv_taps(s, kd, ks);
     const int x = threadIdx.x & 63, yb = threadIdx.x >> 6;
     float lxx[4], lxy[4], lyy[4];
-    ak_load_tile(Lx, rows, cols, x0, y0, s, 1, in);
+    ak_load_tile((const float*)L.Lx[lv], rows, cols, x0, y0, s, 1, in);
     __syncthreads();
     ak_row_pass(in, s, kd, tmp);
     __syncthreads();
@@ -485,12 +531,13 @@ ak_det_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int ro
     __syncthreads();
     for (int j = 0; j < 4; ++j) lxy[j] = ak_col_pass(tmp, s, kd, yb + 4 * j, x);
     __syncthreads();
-    ak_load_tile(Ly, rows, cols, x0, y0, s, 1, in);
+    ak_load_tile((const float*)L.Ly[lv], rows, cols, x0, y0, s, 1, in);
     __syncthreads();
     ak_row_pass(in, s, ks, tmp);
     __syncthreads();
     for (int j = 0; j < 4; ++j) lyy[j] = ak_col_pass(tmp, s, kd, yb + 4 * j, x);
     const float s4 = (float)(s * s * s * s);
+    float* __restrict__ Ldet = L.Ldet[lv];
     if (x0 + x < cols)
         for (int j = 0; j < 4; ++j) {
             const int gy = y0 + yb + 4 * j;
@@ -499,8 +546,11 @@ ak_det_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int ro
 }
 
 __global__ void __launch_bounds__(256)
-ak_candidates_kernel(const float* __restrict__ Ldet, int rows, int cols, int border, float thr, int level,
-                     int* __restrict__ n_cand, float* __restrict__ cand, int cap) {
+ak_candidates_kernel(ak_levels_all L, float thr, int* __restrict__ n_cand, float* __restrict__ cand, int cap) {
+    const int level = blockIdx.z;
+    const int rows = L.rows[level], cols = L.cols[level], border = L.border[level];
+    const float* __restrict__ Ldet = L.Ldet[level];
+    if (border + 1 >= rows) return;   // "if border is too big we shouldn't search any keypoints"
     const int x = border + blockIdx.x * 64 + (threadIdx.x & 63), y = border + blockIdx.y * 4 + (threadIdx.x >> 6);
     bool hit = false;
     const float* c = Ldet + (size_t)min(y, rows - 1) * cols + min(x, cols - 1);
@@ -759,7 +809,7 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
             HIP_TRY(ctx, hipMemcpy(S->tau_dev + (size_t)i * AK_MAX_STEPS, S->lv[i].tau, (size_t)S->lv[i].nsteps * 4,
                                    hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)ak_level_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     2 * AK_SMALL_PX * 4));
+                                     AK_SMALL_LDS_FLOATS * 4));
     return IMATCH_OK;
 }
 
@@ -842,7 +892,7 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     }
     (void)sstride;
     auto grid = [](int rows, int cols) { return dim3((cols + AK_TW - 1) / AK_TW, (rows + AK_TH - 1) / AK_TH); };
-    ak_taps g9, g5, kd, ks;
+    ak_taps g9, g5;
     gauss_taps(9, 1.6f, &g9);
     gauss_taps(5, 1.0, &g5);
     // A2: first level, contrast factor
@@ -865,8 +915,9 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
         // resize(): scale = 1 / (dsize / ssize) per axis; the 2 x 2 box path when both are exactly 2
         const double sc_x = 1. / ((double)e->cols / p->cols), sc_y = 1. / ((double)e->rows / p->rows);
         const int fast = fabs(sc_x - 2.0) < 2.220446049250313e-16 && fabs(sc_y - 2.0) < 2.220446049250313e-16;
-        if (e->rows * e->cols <= AK_SMALL_PX && e->rows >= 2 && e->cols >= 2) {
-            hipLaunchKernelGGL(ak_level_small_kernel, dim3(1), dim3(1024), (size_t)2 * e->rows * e->cols * 4, st, p->Lt, p->rows,
+        if (e->rows * e->cols <= AK_SMALL_PX && 2 * e->rows * e->cols + 4 * e->cols <= AK_SMALL_LDS_FLOATS && e->rows >= 2 &&
+            e->cols >= 2) {
+            hipLaunchKernelGGL(ak_level_small_kernel, dim3(1), dim3(1024), ((size_t)2 * e->rows * e->cols + 4 * e->cols) * 4, st, p->Lt, p->rows,
                                p->cols, e->octave > p->octave ? 1 : 0, fast, sc_x, sc_y, e->rows, e->cols, g5, S->kc, e->octave, e->nsteps,
                                S->tau_dev + (size_t)i * AK_MAX_STEPS, e->Lt, e->Lsmooth);
             continue;
@@ -890,19 +941,26 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     }
     // A3 + candidates
     HIP_TRY(ctx, hipMemsetAsync(S->n_cand, 0, 4, st));
-    for (int i = 0; i < S->n_levels; ++i) {
-        ak_level* e = &S->lv[i];
-        const int s = e->sigma_size;
-        const float wgt = 10.0f / 3.0f, norm = 1.0f / (2.0f * s * (wgt + 2.0f));
-        kd.n = 2; kd.off[0] = -s; kd.off[1] = s; kd.k[0] = -1.f; kd.k[1] = 1.f;
-        ks.n = 3; ks.off[0] = -s; ks.off[1] = 0; ks.off[2] = s; ks.k[0] = norm; ks.k[1] = wgt * norm; ks.k[2] = norm;
-        const dim3 g = grid(e->rows, e->cols);
-        hipLaunchKernelGGL(ak_deriv1_kernel, g, dim3(256), 0, st, e->Lsmooth, e->rows, e->cols, s, kd, ks, e->Lx, e->Ly);
-        hipLaunchKernelGGL(ak_det_kernel, g, dim3(256), 0, st, e->Lx, e->Ly, e->rows, e->cols, s, kd, ks, e->Ldet);
-        const int iw = e->cols - 2 * e->border, ih = e->rows - 2 * e->border;
-        if (e->border + 1 < e->rows && iw > 0 && ih > 0)
-            hipLaunchKernelGGL(ak_candidates_kernel, dim3((iw + 63) / 64, (ih + 3) / 4), dim3(256), 0, st, e->Ldet, e->rows,
-                               e->cols, e->border, (float)P->threshold, i, S->n_cand, S->cand, S->cand_cap);
+    {
+        ak_levels_all LA;
+        LA.n = S->n_levels;
+        int max_rows = 1, max_cols = 1, max_iw = 0, max_ih = 0;
+        for (int i = 0; i < AK_MAX_LEVELS; ++i) {
+            const bool ok = i < S->n_levels;
+            const ak_level* e = &S->lv[ok ? i : 0];
+            LA.rows[i] = e->rows; LA.cols[i] = e->cols; LA.s[i] = e->sigma_size; LA.border[i] = e->border;
+            LA.Lsmooth[i] = e->Lsmooth; LA.Lx[i] = e->Lx; LA.Ly[i] = e->Ly; LA.Ldet[i] = e->Ldet;
+            if (ok) {
+                max_rows = std::max(max_rows, e->rows); max_cols = std::max(max_cols, e->cols);
+                max_iw = std::max(max_iw, e->cols - 2 * e->border); max_ih = std::max(max_ih, e->rows - 2 * e->border);
+            }
+        }
+        const dim3 g((max_cols + AK_TW - 1) / AK_TW, (max_rows + AK_TH - 1) / AK_TH, S->n_levels);
+        hipLaunchKernelGGL(ak_deriv1_kernel, g, dim3(256), 0, st, LA);
+        hipLaunchKernelGGL(ak_det_kernel, g, dim3(256), 0, st, LA);
+        if (max_iw > 0 && max_ih > 0)
+            hipLaunchKernelGGL(ak_candidates_kernel, dim3((max_iw + 63) / 64, (max_ih + 3) / 4, S->n_levels), dim3(256), 0, st, LA,
+                               (float)P->threshold, S->n_cand, S->cand, S->cand_cap);
     }
     HIP_TRY(ctx, hipGetLastError());
     static const bool timing = getenv("IMATCH_TIMING") != nullptr;
