@@ -593,6 +593,9 @@ __device__ __forceinline__ float ak_angle_deg(float y, float x) {
     return a;
 }
 
+__constant__ signed char ak_ori_di[112], ak_ori_dj[112];
+__constant__ float ak_ori_w[112];
+
 __global__ void __launch_bounds__(256)
 ak_orient_kernel(float* __restrict__ kp, int n, ak_levels_dev L) {
     __shared__ float resX[4][112], resY[4][112];
@@ -607,18 +610,11 @@ ak_orient_kernel(float* __restrict__ kp, int n, ak_levels_dev L) {
     const int rows = L.rows[lvl], cols = L.cols[lvl];
     const int scale = __float2int_rn(0.5f * k[2] / ratio);
     const int x0 = __float2int_rn(k[0] / ratio), y0 = __float2int_rn(k[1] / ratio);
-    // the 109 samples with di^2 + dj^2 < 36, enumerated di-major as the table of OpenSURF's gauss25 weights is walked
-    for (int t = lane; t < 169 && live; t += 64) {
-        const int di = t / 13 - 6, dj = t % 13 - 6;
-        if (di * di + dj * dj >= 36) continue;
-        // rank of (di, dj) among the kept samples
-        int r = 0;
-        for (int a = -6; a < di; ++a)
-            for (int b = -6; b <= 6; ++b) r += (a * a + b * b < 36);
-        for (int b = -6; b < dj; ++b) r += (di * di + b * b < 36);
+    // the 109 samples with di^2 + dj^2 < 36, di-major, with OpenSURF's gauss25 weights (table filled on the host)
+    for (int r = lane; r < 109 && live; r += 64) {
+        const int di = ak_ori_di[r], dj = ak_ori_dj[r];
         const int y = min(max(y0 + dj * scale, 0), rows - 1), x = min(max(x0 + di * scale, 0), cols - 1);
-        const double g = exp(-(double)(di * di + dj * dj) / 12.5) / (2.0 * M_PI * 6.25);
-        const float wgt = (float)(floor(g * 1e8 + 0.5) / 1e8);
+        const float wgt = ak_ori_w[r];
         const float rx = wgt * L.Lx[lvl][(size_t)y * cols + x], ry = wgt * L.Ly[lvl][(size_t)y * cols + x];
         resX[w][r] = rx;
         resY[w][r] = ry;
@@ -808,6 +804,21 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
         if (S->lv[i].nsteps > 0)
             HIP_TRY(ctx, hipMemcpy(S->tau_dev + (size_t)i * AK_MAX_STEPS, S->lv[i].tau, (size_t)S->lv[i].nsteps * 4,
                                    hipMemcpyHostToDevice));
+    {
+        signed char di[112] = {0}, dj[112] = {0};
+        float wt[112] = {0};
+        int k = 0;
+        for (int i = -6; i <= 6; ++i)
+            for (int j = -6; j <= 6; ++j)
+                if (i * i + j * j < 36) {
+                    const double g = exp(-(double)(i * i + j * j) / 12.5) / (2.0 * M_PI * 6.25);
+                    di[k] = (signed char)i; dj[k] = (signed char)j;
+                    wt[k++] = (float)(floor(g * 1e8 + 0.5) / 1e8);   // the table's 8 decimals
+                }
+        HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(ak_ori_di), di, sizeof di));
+        HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(ak_ori_dj), dj, sizeof dj));
+        HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(ak_ori_w), wt, sizeof wt));
+    }
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)ak_level_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      AK_SMALL_LDS_FLOATS * 4));
     return IMATCH_OK;
@@ -835,42 +846,34 @@ struct ak_level_pts {
     }
 };
 
-// raw: n records of AK_CAND_FLOATS in any order -> per level, sorted by (y, x) with a counting sort on y
-static void bucket_candidates(const float* raw, int n, const imatch_akaze_state* S, std::vector<ak_level_pts>& L) {
-    L.assign((size_t)S->n_levels, ak_level_pts());
-    std::vector<int> count((size_t)S->n_levels, 0);
-    for (int i = 0; i < n; ++i) count[(int)raw[(size_t)i * AK_CAND_FLOATS]]++;
-    for (int l = 0; l < S->n_levels; ++l) {
-        ak_level_pts& P = L[l];
-        P.rows = S->lv[l].rows;
-        P.row_start.assign((size_t)P.rows + 1, 0);
-        P.x.resize(count[l]); P.y.resize(count[l]); P.v.resize((size_t)count[l] * 9); P.alive.assign(count[l], 0);
-    }
+// raw: n records of AK_CAND_FLOATS in any order -> the points of level l, sorted by (y, x): counting sort on y, insertion
+// by x inside a row (rows hold a handful of points). Each level is built by its own task.
+static void bucket_level(const float* raw, int n, int l, int rows, ak_level_pts& P) {
+    P.rows = rows;
+    P.row_start.assign((size_t)rows + 1, 0);
+    int count = 0;
     for (int i = 0; i < n; ++i) {
         const float* r = raw + (size_t)i * AK_CAND_FLOATS;
-        L[(int)r[0]].row_start[(int)r[2] + 1]++;
+        if ((int)r[0] == l) { P.row_start[(int)r[2] + 1]++; ++count; }
     }
-    for (auto& P : L)
-        for (int y = 0; y < P.rows; ++y) P.row_start[y + 1] += P.row_start[y];
-    std::vector<std::vector<int>> fill((size_t)S->n_levels);
-    for (int l = 0; l < S->n_levels; ++l) fill[l].assign(L[l].row_start.begin(), L[l].row_start.end() - 1);
+    P.x.resize(count); P.y.resize(count); P.v.resize((size_t)count * 9); P.alive.assign(count, 0);
+    for (int y = 0; y < rows; ++y) P.row_start[y + 1] += P.row_start[y];
+    std::vector<int> fill(P.row_start.begin(), P.row_start.end() - 1);
     for (int i = 0; i < n; ++i) {
         const float* r = raw + (size_t)i * AK_CAND_FLOATS;
-        ak_level_pts& P = L[(int)r[0]];
+        if ((int)r[0] != l) continue;
         const int yy = (int)r[2], xx = (int)r[1];
-        // insertion by x inside the row (rows hold a handful of points)
-        int p = fill[(int)r[0]][yy]++;
+        int p = fill[yy]++;
         while (p > P.row_start[yy] && P.x[p - 1] > xx) {
             P.x[p] = P.x[p - 1];
             memcpy(&P.v[(size_t)p * 9], &P.v[(size_t)(p - 1) * 9], 36);
             --p;
         }
-        P.x[p] = xx; P.y[p] = yy;
+        P.x[p] = xx;
         memcpy(&P.v[(size_t)p * 9], r + 3, 36);
     }
-    for (auto& P : L)   // y follows from the row index (the insertion above only moved x and v)
-        for (int yy = 0; yy < P.rows; ++yy)
-            for (int p = P.row_start[yy]; p < P.row_start[yy + 1]; ++p) P.y[p] = yy;
+    for (int yy = 0; yy < rows; ++yy)
+        for (int p = P.row_start[yy]; p < P.row_start[yy + 1]; ++p) P.y[p] = yy;
 }
 
 static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int stride, const imatch_akaze_params* P) {
@@ -975,15 +978,22 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (n_cand > S->cand_cap)
         return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: %d candidates exceed the list of %d", n_cand, S->cand_cap);
-    std::vector<float> raw((size_t)n_cand * AK_CAND_FLOATS);
+    const float* raw = nullptr;   // the records stay in the pinned block until the levels are built from them
     const auto t_gpu = now();
-    if (n_cand) HIP_TRY(ctx, hipMemcpy(raw.data(), S->cand, raw.size() * 4, hipMemcpyDeviceToHost));
+    if (n_cand) {
+        const size_t rb = (size_t)n_cand * AK_CAND_FLOATS * 4;
+        rc = imatch_hs_reserve(ctx, rb);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->hs, S->cand, rb, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        raw = (const float*)ctx->hs;
+    }
     const auto t_dl = now();
-    std::vector<ak_level_pts> LP;
-    bucket_candidates(raw.data(), n_cand, S, LP);
+    std::vector<ak_level_pts> LP((size_t)S->n_levels);
     // same level: row-major scan, the first kept neighbour decides (levels are independent of one another here)
     imatch_parallel_for(ctx, S->n_levels, [&](int l) {
         ak_level_pts& P = LP[l];
+        bucket_level(raw, n_cand, l, S->lv[l].rows, P);
         const int r = S->lv[l].sigma_size;
         for (int p = 0; p < (int)P.x.size(); ++p) {
             const int nb = P.find(P.x[p], P.y[p], r);
@@ -1061,13 +1071,20 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
         L.rows[i] = ok ? S->lv[i].rows : 1; L.cols[i] = ok ? S->lv[i].cols : 1; L.ratio[i] = ok ? S->lv[i].ratio : 1.f;
         L.Lx[i] = ok ? S->lv[i].Lx : nullptr; L.Ly[i] = ok ? S->lv[i].Ly : nullptr;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(S->kp_dev, kdev.data(), kdev.size() * 4, hipMemcpyHostToDevice, st));
+    // records up and results down through the context's pinned block (pageable copies take the slow staged path)
+    const size_t kb = (size_t)n * 8 * 4, db = (size_t)n * 64 * 4;
+    rc = imatch_hs_reserve(ctx, kb + db);
+    if (rc) return rc;
+    memcpy(ctx->hs, kdev.data(), kb);
+    HIP_TRY(ctx, hipMemcpyAsync(S->kp_dev, ctx->hs, kb, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(ak_orient_kernel, dim3((n + 3) / 4), dim3(256), 0, st, S->kp_dev, n, L);
     hipLaunchKernelGGL(ak_msurf_kernel, dim3((n + 3) / 4), dim3(256), 0, st, S->kp_dev, n, L, S->desc_dev);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(kdev.data(), S->kp_dev, kdev.size() * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(S->desc.data(), S->desc_dev, (size_t)n * 64 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs, S->kp_dev, kb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->hs + kb, S->desc_dev, db, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    memcpy(kdev.data(), ctx->hs, kb);
+    memcpy(S->desc.data(), (char*)ctx->hs + kb, db);
     for (int i = 0; i < n; ++i) memcpy(S->kp.data() + (size_t)i * 7, kdev.data() + (size_t)i * 8, 28);
     if (timing)
         fprintf(stderr, "[imatch] akaze host phases: wait for GPU %.3f ms, candidates down %.3f ms (%d), filter + sub-pixel %.3f ms, "

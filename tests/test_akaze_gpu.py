@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _compare(ctx, img, planes=True):
-    want = oracle.akaze(img, keep_levels=planes)
-    kp, desc = ctx.akaze_extract(img, AkazeParams(clahe=False))
+def _compare(ctx, img, planes=True, threshold=0.0005, n_octaves=4, n_layers=5):
+    want = oracle.akaze(img, threshold, n_octaves, n_layers, keep_levels=planes)
+    kp, desc = ctx.akaze_extract(img, AkazeParams(threshold, n_octaves, n_layers, clahe=False))
     if planes:
         assert ctx.akaze_levels() == len(want.levels)
         assert ctx.akaze_debug_layer(5, 0)[0, 0] == np.float32(want.kcontrast)
@@ -47,6 +47,15 @@ def test_other_sizes(ctx):
     m = synth.synth_map(1024, seed=9)
     for h, w in ((240, 320), (88, 200), (360, 648), (321, 448), (479, 641), (250, 333), (1024, 1024)):   # odd sizes: general INTER_AREA
         _compare(ctx, np.ascontiguousarray(m[:h, :w]), planes=(h < 500))
+
+
+def test_other_parameters(ctx):
+    """Other thresholds, octave and sublevel counts than the reference's call (sigma_size reaches 5 with 3 sublevels... the
+    FED cycles and borders change with them)."""
+    img = np.ascontiguousarray(synth.synth_map(1024, seed=12)[:384, :512])
+    _compare(ctx, img, threshold=0.001, n_octaves=2, n_layers=3)
+    _compare(ctx, img, threshold=0.0002, n_octaves=3, n_layers=4)
+    _compare(ctx, img, threshold=0.0005, n_octaves=1, n_layers=1)
 
 
 def test_flat_and_tiny_images(ctx):
