@@ -52,10 +52,10 @@ struct imatch_akaze_state {
     float* kc;               // device: contrast factor per octave
     float* tau_dev;          // device [levels][AK_MAX_STEPS]: the FED cycles
     int* n_cand;             // device counter
-    float* cand;             // device [cap][AK_CAND_FLOATS]
+    float* cand;             // device [cap][AK_CAND_FLOATS]; its own allocation, grown when a scan overflows it
     int cand_cap;
-    float* kp_dev;           // device [kp_cap][8]: x, y, size, angle, response, octave, level, pad
-    float* desc_dev;         // device [kp_cap][64]
+    float* kp_dev;           // device [kp_cap][8]: x, y, size, angle, response, octave, level, pad; own allocation
+    float* desc_dev;         // device [kp_cap][64], behind kp_dev
     int kp_cap;
     // last result (host)
     std::vector<float> kp, desc;
@@ -65,6 +65,8 @@ struct imatch_akaze_state {
 void imatch_akaze_state_free(imatch_ctx* ctx) {
     if (!ctx || !ctx->akaze) return;
     if (ctx->akaze->arena) (void)hipFree(ctx->akaze->arena);
+    if (ctx->akaze->cand) (void)hipFree(ctx->akaze->cand);
+    if (ctx->akaze->kp_dev) (void)hipFree(ctx->akaze->kp_dev);
     delete ctx->akaze;
     ctx->akaze = nullptr;
 }
@@ -728,6 +730,30 @@ static void gauss_taps(int n, double sigma, ak_taps* k) {
     for (int i = 0; i < n; ++i) k->off[i] = i - n2;
 }
 
+// The candidate list and the keypoint / descriptor block are sized from the image and grow on demand (a noise image has
+// up to one 3 x 3 maximum per four pixels and level).
+static int akaze_grow_lists(imatch_ctx* ctx, int cand_cap, int kp_cap) {
+    imatch_akaze_state* S = ctx->akaze;
+    if (cand_cap > S->cand_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (S->cand) (void)hipFree(S->cand);
+        S->cand = nullptr; S->cand_cap = 0;
+        if (hipMalloc((void**)&S->cand, (size_t)cand_cap * AK_CAND_FLOATS * 4) != hipSuccess)
+            return imatch_set_err(ctx, IMATCH_ENOMEM, "AKAZE candidate list of %d records", cand_cap);
+        S->cand_cap = cand_cap;
+    }
+    if (kp_cap > S->kp_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (S->kp_dev) (void)hipFree(S->kp_dev);
+        S->kp_dev = nullptr; S->kp_cap = 0;
+        if (hipMalloc((void**)&S->kp_dev, (size_t)kp_cap * (8 + 64) * 4) != hipSuccess)
+            return imatch_set_err(ctx, IMATCH_ENOMEM, "AKAZE keypoint block of %d records", kp_cap);
+        S->desc_dev = S->kp_dev + (size_t)kp_cap * 8;
+        S->kp_cap = kp_cap;
+    }
+    return IMATCH_OK;
+}
+
 static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
     imatch_akaze_state* S = ctx->akaze;
     if (S && S->h == h && S->w == w && S->omax == omax && S->nsub == nsub) return IMATCH_OK;
@@ -737,7 +763,7 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
     }
     S = new (std::nothrow) imatch_akaze_state();
     if (!S) return imatch_set_err(ctx, IMATCH_ENOMEM, "host allocation failed");
-    S->arena = nullptr; S->n_levels = 0; S->n_kp = 0;
+    S->arena = nullptr; S->cand = nullptr; S->kp_dev = nullptr; S->desc_dev = nullptr; S->n_levels = 0; S->n_kp = 0;
     ctx->akaze = S;
     S->h = h; S->w = w; S->omax = omax; S->nsub = nsub;
     const float soffset = 1.6f, derivative_factor = 1.5f, smax = 12.0f * sqrtf(2.0f);
@@ -772,9 +798,8 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
     const size_t px0 = up((size_t)h * w * 4);
     size_t total = 2 * px0 + up((size_t)h * w) + up(4096 * 1280) + 4096 + up((size_t)AK_MAX_LEVELS * AK_MAX_STEPS * 4);
     for (int i = 0; i < S->n_levels; ++i) total += 5 * up((size_t)S->lv[i].rows * S->lv[i].cols * 4);
-    S->cand_cap = std::max(4096, h * w / 16);
-    S->kp_cap = S->cand_cap;
-    total += up((size_t)S->cand_cap * AK_CAND_FLOATS * 4) + up((size_t)S->kp_cap * 8 * 4) + up((size_t)S->kp_cap * 64 * 4);
+    S->cand_cap = 0;
+    S->kp_cap = 0;
     if (hipMalloc((void**)&S->arena, total) != hipSuccess) {
         S->arena = nullptr;
         imatch_akaze_state_free(ctx);
@@ -797,9 +822,11 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
         e->Lt = (float*)take(b); e->Lsmooth = (float*)take(b); e->Lx = (float*)take(b); e->Ly = (float*)take(b);
         e->Ldet = (float*)take(b);
     }
-    S->cand = (float*)take((size_t)S->cand_cap * AK_CAND_FLOATS * 4);
-    S->kp_dev = (float*)take((size_t)S->kp_cap * 8 * 4);
-    S->desc_dev = (float*)take((size_t)S->kp_cap * 64 * 4);
+    const int rc = akaze_grow_lists(ctx, std::max(4096, (int)std::min<int64_t>((int64_t)h * w / 16, 1 << 26)), 4096);
+    if (rc) {
+        imatch_akaze_state_free(ctx);
+        return rc;
+    }
     for (int i = 0; i < S->n_levels; ++i)
         if (S->lv[i].nsteps > 0)
             HIP_TRY(ctx, hipMemcpy(S->tau_dev + (size_t)i * AK_MAX_STEPS, S->lv[i].tau, (size_t)S->lv[i].nsteps * 4,
@@ -943,11 +970,11 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
         }
     }
     // A3 + candidates
-    HIP_TRY(ctx, hipMemsetAsync(S->n_cand, 0, 4, st));
+    ak_levels_all LA;
+    int max_iw = 0, max_ih = 0;
     {
-        ak_levels_all LA;
         LA.n = S->n_levels;
-        int max_rows = 1, max_cols = 1, max_iw = 0, max_ih = 0;
+        int max_rows = 1, max_cols = 1;
         for (int i = 0; i < AK_MAX_LEVELS; ++i) {
             const bool ok = i < S->n_levels;
             const ak_level* e = &S->lv[ok ? i : 0];
@@ -961,11 +988,17 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
         const dim3 g((max_cols + AK_TW - 1) / AK_TW, (max_rows + AK_TH - 1) / AK_TH, S->n_levels);
         hipLaunchKernelGGL(ak_deriv1_kernel, g, dim3(256), 0, st, LA);
         hipLaunchKernelGGL(ak_det_kernel, g, dim3(256), 0, st, LA);
+    }
+    auto scan = [&]() -> int {
+        HIP_TRY(ctx, hipMemsetAsync(S->n_cand, 0, 4, st));
         if (max_iw > 0 && max_ih > 0)
             hipLaunchKernelGGL(ak_candidates_kernel, dim3((max_iw + 63) / 64, (max_ih + 3) / 4, S->n_levels), dim3(256), 0, st, LA,
                                (float)P->threshold, S->n_cand, S->cand, S->cand_cap);
-    }
-    HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipGetLastError());
+        return IMATCH_OK;
+    };
+    rc = scan();
+    if (rc) return rc;
     static const bool timing = getenv("IMATCH_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -976,8 +1009,15 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     int n_cand = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&n_cand, S->n_cand, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (n_cand > S->cand_cap)
-        return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: %d candidates exceed the list of %d", n_cand, S->cand_cap);
+    if (n_cand > S->cand_cap) {   // the scan counted them all: grow the list and scan again (the planes are still there)
+        rc = akaze_grow_lists(ctx, n_cand + n_cand / 8, 0);
+        if (rc) return rc;
+        rc = scan();
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(&n_cand, S->n_cand, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (n_cand > S->cand_cap) return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: candidate list overflow");
+    }
     const float* raw = nullptr;   // the records stay in the pinned block until the levels are built from them
     const auto t_gpu = now();
     if (n_cand) {
@@ -1062,7 +1102,8 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     S->kp.assign((size_t)n * 7, 0.f);
     S->desc.assign((size_t)n * 64, 0.f);
     if (n == 0) return IMATCH_OK;
-    if (n > S->kp_cap) return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: %d keypoints exceed the list of %d", n, S->kp_cap);
+    rc = akaze_grow_lists(ctx, 0, n + n / 4);
+    if (rc) return rc;
     // A6, A7 on the device
     ak_levels_dev L;
     L.n = S->n_levels;

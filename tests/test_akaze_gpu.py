@@ -58,6 +58,14 @@ def test_other_parameters(ctx):
     _compare(ctx, img, threshold=0.0005, n_octaves=1, n_layers=1)
 
 
+def test_noise_image_overflows_and_regrows_the_candidate_list(ctx):
+    """White noise has far more 3 x 3 maxima than the list sized from the image holds: the scan is repeated into a larger
+    list, the result is the oracle's."""
+    img = np.random.default_rng(5).integers(0, 256, (480, 640), dtype=np.uint8)
+    kp, _ = _compare(ctx, img, planes=False, threshold=1e-6)
+    assert len(kp) > 480 * 640 // 16 // 4
+
+
 def test_flat_and_tiny_images(ctx):
     kp, desc = ctx.akaze_extract(np.full((120, 160), 77, np.uint8), AkazeParams(clahe=False))
     assert kp.shape == (0, 7) and desc.shape == (0, 64)
