@@ -431,7 +431,7 @@ def main():
         finished = threading.Event()
 
         def watchdog():
-            if not finished.wait(float(os.environ.get("IMATCH_BENCH_EXTRA_TIMEOUT", "240"))):
+            if not finished.wait(float(os.environ.get("IMATCH_BENCH_EXTRA_TIMEOUT", "120"))):
                 emit({"error": "the sharded-map loop did not finish in time; the headline does not depend on it"})
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
