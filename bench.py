@@ -24,7 +24,7 @@ max over ranks between two barriers). What happens to the map depends on its siz
               maps of 5M-20M descriptors).
 In replicated mode a short sharded loop is run AFTER the headline is final and reported beside it as "sharded_map":
 one batch compared bit for bit with the whole-map result, then 10 timed steps. It runs under a watchdog
-(IMATCH_BENCH_EXTRA_TIMEOUT seconds, default 240): a failure or a stuck collective there is reported in that
+(IMATCH_BENCH_EXTRA_TIMEOUT seconds, default 120): a failure or a stuck collective there is reported in that
 field and cannot change or withhold `value`. IMATCH_BENCH_SHARDED_EXTRA=0 skips it.
 
 One JSON line on stdout (rank 0). Progress goes to stderr."""
