@@ -734,6 +734,13 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     static const unsigned young_wg = getenv("IMATCH_KNN_YOUNG_WG") ? (unsigned)atoi(getenv("IMATCH_KNN_YOUNG_WG")) : 0xffffffffu;
     const bool use16 = mfma16 && QB == 4;
     const int TNs = (use16 && tn_env == 128 && t->n_pad % 128 == 0) ? 128 : 64;
+    // a single frame's few thousand queries against a map of up to a million rows: 256-query workgroups (QB16 = 4),
+    // twice the workgroups per chunk, so the chunks are twice as long and the resident-query prologue and the partial
+    // lists weigh half as much (0.284 -> 0.242 ms at 2951 x 236k, 0.169 -> 0.127 ms at 2951 x 59k; from 8192 queries
+    // or 5 M rows on the 512-query form is faster, profiles/r1_knn_shapes.txt)
+    static const int64_t q16_small = getenv("IMATCH_KNN_Q16_SMALL") ? atoll(getenv("IMATCH_KNN_Q16_SMALL")) : 6144;
+    const bool small16 = use16 && TNs == 128 && q->n <= q16_small && t->n_pad <= (1 << 20);
+    if (small16) QB = 2;   // qtile below = 4 * 32 * 2 = 4 waves x 16 * 4 queries
     const int qtile = 4 * 32 * QB;
     const int64_t Qpad = q->n_pad;  // multiple of 1024, so of every qtile
     const int nQt = (int)((q->n + qtile - 1) / qtile);
@@ -763,7 +770,10 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
         const unsigned grid = (unsigned)(nQt * nChunks);
 #define LAUNCH16(TN_, XM_) hipLaunchKernelGGL((knn2_kernel16<8, TN_, XM_>), dim3(grid), dim3(256), 0, ctx->stream, \
         (const uint4*)q->desc, (const uint4*)t->desc, t->hneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr, young, young_wg)
-        if (TNs == 128 && xmask == 3) LAUNCH16(128, 3);
+        if (small16)
+            hipLaunchKernelGGL((knn2_kernel16<4, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)q->desc,
+                               (const uint4*)t->desc, t->hneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr, young, young_wg);
+        else if (TNs == 128 && xmask == 3) LAUNCH16(128, 3);
         else if (TNs == 128) LAUNCH16(128, 7);
         else LAUNCH16(64, 3);
 #undef LAUNCH16
