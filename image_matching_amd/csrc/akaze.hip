@@ -547,36 +547,52 @@ ak_det_kernel(ak_levels_all L) {
         }
 }
 
+// A workgroup scans a 64 x 32 window (8 rows per thread) and reserves the slots of ALL its hits with one global atomic:
+// atomics on the single counter complete at about one per 20 ns, and a launch finds tens of thousands of candidates.
+#define AK_CAND_ROWS 8
 __global__ void __launch_bounds__(256)
 ak_candidates_kernel(ak_levels_all L, float thr, int* __restrict__ n_cand, float* __restrict__ cand, int cap) {
+    __shared__ int blk_count, blk_base;
     const int level = blockIdx.z;
     const int rows = L.rows[level], cols = L.cols[level], border = L.border[level];
     const float* __restrict__ Ldet = L.Ldet[level];
-    if (border + 1 >= rows) return;   // "if border is too big we shouldn't search any keypoints"
-    const int x = border + blockIdx.x * 64 + (threadIdx.x & 63), y = border + blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool hit = false;
-    const float* c = Ldet + (size_t)min(y, rows - 1) * cols + min(x, cols - 1);
-    float v = 0.f;
-    if (x < cols - border && y < rows - border) {
-        v = *c;
-        hit = v > thr && v > c[-1] && v > c[1] && v > c[-cols - 1] && v > c[-cols] && v > c[-cols + 1] && v > c[cols - 1] &&
-              v > c[cols] && v > c[cols + 1];
+    if (border + 1 >= rows) return;   // "if border is too big we shouldn't search any keypoints" (uniform per block)
+    const int x = border + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yb = border + blockIdx.y * (4 * AK_CAND_ROWS) + (threadIdx.x >> 6) * AK_CAND_ROWS;
+    if (blockIdx.x * 64 >= cols - 2 * border || blockIdx.y * (4 * AK_CAND_ROWS) >= rows - 2 * border) return;   // uniform
+    if (threadIdx.x == 0) blk_count = 0;
+    __syncthreads();
+    unsigned hits = 0;
+    if (x < cols - border)
+        for (int r = 0; r < AK_CAND_ROWS; ++r) {
+            const int y = yb + r;
+            if (y >= rows - border) break;
+            const float* c = Ldet + (size_t)y * cols + x;
+            const float v = *c;
+            if (v > thr && v > c[-1] && v > c[1] && v > c[-cols - 1] && v > c[-cols] && v > c[-cols + 1] && v > c[cols - 1] &&
+                v > c[cols] && v > c[cols + 1])
+                hits |= 1u << r;
+        }
+    int mine = 0;
+    const int n_mine = __popc(hits);
+    if (n_mine) mine = atomicAdd(&blk_count, n_mine);   // LDS
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_count) blk_base = atomicAdd(n_cand, blk_count);
+    __syncthreads();
+    int slot = blk_base + mine;
+    for (int r = 0; r < AK_CAND_ROWS; ++r) {
+        if (!(hits >> r & 1)) continue;
+        if (slot < cap) {
+            const int y = yb + r;
+            const float* c = Ldet + (size_t)y * cols + x;
+            float* o = cand + (size_t)slot * AK_CAND_FLOATS;
+            o[0] = (float)level; o[1] = (float)x; o[2] = (float)y;
+            o[3] = c[-cols - 1]; o[4] = c[-cols]; o[5] = c[-cols + 1];
+            o[6] = c[-1]; o[7] = *c; o[8] = c[1];
+            o[9] = c[cols - 1]; o[10] = c[cols]; o[11] = c[cols + 1];
+        }
+        ++slot;
     }
-    // one atomic per wavefront reserves the slots of its hits (the list's order is settled on the host)
-    const unsigned long long m = __ballot(hit);
-    if (!m) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_cand, __popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (!hit) return;
-    const int slot = base + __popcll(m & ((1ull << lane) - 1));
-    if (slot >= cap) return;
-    float* o = cand + (size_t)slot * AK_CAND_FLOATS;
-    o[0] = (float)level; o[1] = (float)x; o[2] = (float)y;
-    o[3] = c[-cols - 1]; o[4] = c[-cols]; o[5] = c[-cols + 1];
-    o[6] = c[-1]; o[7] = v; o[8] = c[1];
-    o[9] = c[cols - 1]; o[10] = c[cols]; o[11] = c[cols + 1];
 }
 
 // ---- orientation + descriptor: one wavefront per keypoint -----------------------------------------------------------
@@ -992,7 +1008,7 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     auto scan = [&]() -> int {
         HIP_TRY(ctx, hipMemsetAsync(S->n_cand, 0, 4, st));
         if (max_iw > 0 && max_ih > 0)
-            hipLaunchKernelGGL(ak_candidates_kernel, dim3((max_iw + 63) / 64, (max_ih + 3) / 4, S->n_levels), dim3(256), 0, st, LA,
+            hipLaunchKernelGGL(ak_candidates_kernel, dim3((max_iw + 63) / 64, (max_ih + 4 * AK_CAND_ROWS - 1) / (4 * AK_CAND_ROWS), S->n_levels), dim3(256), 0, st, LA,
                                (float)P->threshold, S->n_cand, S->cand, S->cand_cap);
         HIP_TRY(ctx, hipGetLastError());
         return IMATCH_OK;
