@@ -559,7 +559,7 @@ ak_candidates_kernel(ak_levels_all L, float thr, int* __restrict__ n_cand, float
     if (border + 1 >= rows) return;   // "if border is too big we shouldn't search any keypoints" (uniform per block)
     const int x = border + blockIdx.x * 64 + (threadIdx.x & 63);
     const int yb = border + blockIdx.y * (4 * AK_CAND_ROWS) + (threadIdx.x >> 6) * AK_CAND_ROWS;
-    if (blockIdx.x * 64 >= cols - 2 * border || blockIdx.y * (4 * AK_CAND_ROWS) >= rows - 2 * border) return;   // uniform
+    if ((int)blockIdx.x * 64 >= cols - 2 * border || (int)blockIdx.y * (4 * AK_CAND_ROWS) >= rows - 2 * border) return;   // uniform
     if (threadIdx.x == 0) blk_count = 0;
     __syncthreads();
     unsigned hits = 0;

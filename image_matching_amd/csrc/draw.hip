@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256)
 canvas_kernel(const uint8_t* __restrict__ img1, int h1, int w1, const uint8_t* __restrict__ img2, int h2, int w2,
               const int* __restrict__ owner, int H, int W, uint8_t* __restrict__ out) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
+    if (x >= W || y >= H) return;
     const size_t p = (size_t)y * W + x;
     const int i = owner[p];
     uint8_t c0, c1, c2;
