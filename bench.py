@@ -86,6 +86,53 @@ def cpu_baseline(frames, map_desc_sample, n_map, map_xy_sample, ratio, threads):
     }
 
 
+def akaze_extra(ctx, map_img, ratio):
+    """Beside the headline (not part of `value`): the detector the checked-in reference calls (match_finder.py:210-211),
+    one frame at a time as BASELINE configs[0] describes it -- CLAHE + AKAZE of a 640x480 frame, float kNN against the
+    AKAZE descriptors of a 2048x2048 crop of the map, ratio test, homography. A failure here is reported in the block."""
+    try:
+        import image_matching_amd as im
+        from image_matching_amd import synth
+        crop = np.ascontiguousarray(map_img[:2048, :2048])
+        p = im.AkazeParams()
+        t0 = time.perf_counter()
+        ckp, cdesc = ctx.akaze_extract(crop, p)
+        ckp, cdesc = ctx.akaze_extract(crop, p)
+        t_crop = (time.perf_counter() - t0) / 2
+        cset = ctx.fset(cdesc)      # the crop's descriptors stay in HBM, as the ROI's do between re-extractions
+        frames = [synth.synth_frame(crop, 500 + i, size=(480, 640), scale_range=(0.9, 1.1))[0] for i in range(8)]
+        found = 0
+        n_kp = 0
+
+        def one(f, i):
+            kp, desc = ctx.akaze_extract(f, p)
+            idx, dist = ctx.knn2_f32(desc, cset)
+            keep = dist[:, 0].astype(np.float64) < ratio * dist[:, 1].astype(np.float64)
+            q = np.nonzero(keep)[0]
+            H = None
+            if len(q) > 10:
+                H, _ = ctx.homography(kp[q, :2], ckp[idx[q, 0], :2], 0.1, seed=i)
+            return len(kp), H is not None
+        for i, f in enumerate(frames[:2]):
+            one(f, i)
+        t0 = time.perf_counter()
+        reps = 3
+        for r in range(reps):
+            for i, f in enumerate(frames):
+                n, ok = one(f, i)
+                n_kp += n
+                found += ok
+        ms = (time.perf_counter() - t0) / (reps * len(frames)) * 1e3
+        return {"detector": "AKAZE(DESCRIPTOR_KAZE, 0.0005, 4, 5, PM_G2), the call of match_finder.py:210-211",
+                "ms_per_frame": ms, "frames_per_s": 1e3 / ms, "keypoints_per_frame": n_kp / (reps * len(frames)),
+                "crop": "2048x2048, %d keypoints, extracted in %.1f ms" % (len(ckp), t_crop * 1e3),
+                "homographies_found": "%d/%d" % (found, reps * len(frames)),
+                "note": "single-frame calls with host pointers in and out (imatch_akaze_extract, imatch_knn2_fset against the "
+                        "resident crop set, imatch_homography), measured after the timed region; not part of value"}
+    except Exception as e:      # must not take the headline down with it
+        return {"error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -403,6 +450,8 @@ def main():
             out["single_frame"] = {"ms_per_frame": single_ms, "frames_per_s": 1e3 / single_ms,
                                    "note": "one frame at a time through the single-frame entry points, measured after "
                                            "the timed region; not part of value"}
+        if world == 1:
+            out["akaze_path"] = akaze_extra(ctx, map_img, ratio)
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
             n_s = n_map if n_map <= 300_000 else 100_000

@@ -76,6 +76,10 @@ SIGNATURES = {
     "imatch_draw_matches": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int, c_u8p]),
     "imatch_knn2_f32": (ctypes.c_int, [c_vp, c_f32p, c_i64, c_f32p, c_i64, ctypes.c_int, c_i32p, c_f32p]),
+    "imatch_fset_from_host": (ctypes.c_int, [c_vp, c_f32p, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "imatch_fset_count": (c_i64, [c_vp]),
+    "imatch_fset_free": (None, [c_vp]),
+    "imatch_knn2_fset": (ctypes.c_int, [c_vp, c_f32p, c_i64, c_vp, c_i32p, c_f32p]),
     "imatch_akaze_extract": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.POINTER(AkazeParams), ctypes.POINTER(c_i64)]),
     "imatch_akaze_extract_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -191,6 +195,27 @@ class Features:
     def free(self):
         if self._h is not None and self.ctx._h is not None:
             self.ctx.lib.imatch_features_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FSet:
+    """A float descriptor set resident in HBM (the train side of knn2_f32): made once, matched against many times."""
+
+    def __init__(self, ctx, handle, n, d):
+        self.ctx, self._h, self.n, self.d = ctx, handle, int(n), int(d)
+
+    def __len__(self):
+        return self.n
+
+    def free(self):
+        if self._h is not None and self.ctx._h is not None:
+            self.ctx.lib.imatch_fset_free(self._h)
         self._h = None
 
     def __del__(self):
@@ -388,8 +413,28 @@ class Context:
                 self._check(self.lib.imatch_akaze_image(self._h, _ptr(out, c_u8p), img.shape[0], img.shape[1]))
         return kp, desc, out
 
+    def fset(self, desc):
+        """Upload a float descriptor matrix [n, d <= 128] once; pass the result as `t` of knn2_f32."""
+        desc = np.ascontiguousarray(desc, np.float32)
+        if desc.ndim != 2:
+            raise ValueError("expected a 2-D descriptor matrix")
+        h = c_vp()
+        with self.lock:
+            self._check(self.lib.imatch_fset_from_host(self._h, _ptr(desc, c_f32p), desc.shape[0], desc.shape[1],
+                                                       ctypes.byref(h)))
+        return FSet(self, h, desc.shape[0], desc.shape[1])
+
     def knn2_f32(self, q, t):
-        """BFMatcher(NORM_L2).knnMatch(q, t, k=2) for float descriptors -> (idx int32 [Q,2], dist f32 [Q,2])."""
+        """BFMatcher(NORM_L2).knnMatch(q, t, k=2) for float descriptors -> (idx int32 [Q,2], dist f32 [Q,2]).
+        t: a matrix (uploaded for this call) or an FSet (resident)."""
+        if isinstance(t, FSet):
+            q = np.ascontiguousarray(q, np.float32).reshape(-1, t.d)
+            idx = np.empty((len(q), 2), np.int32)
+            dist = np.empty((len(q), 2), np.float32)
+            with self.lock:
+                self._check(self.lib.imatch_knn2_fset(self._h, _ptr(q, c_f32p), len(q), t._h, _ptr(idx, c_i32p),
+                                                      _ptr(dist, c_f32p)))
+            return idx, dist
         q = np.ascontiguousarray(q, np.float32)
         t = np.ascontiguousarray(t, np.float32)
         d = q.shape[1] if q.ndim == 2 else (t.shape[1] if t.ndim == 2 else 64)

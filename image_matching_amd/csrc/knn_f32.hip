@@ -100,10 +100,16 @@ knn2_f32_finish_kernel(const kf_top2* __restrict__ partial, int n_chunks, int64_
     dist[2 * i] = r.d1; dist[2 * i + 1] = r.d2;
 }
 
-extern "C" int imatch_knn2_f32(imatch_ctx* ctx, const float* q, int64_t nq, const float* t, int64_t nt, int d, int32_t* idx,
-                               float* dist) {
-    if (!ctx || nq < 0 || nt < 0 || d < 1 || d > 128 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t))
-        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+struct imatch_fset {
+    imatch_ctx* ctx;
+    float* desc;   // device [n][d], from the context's block pool
+    int64_t n;
+    int d;
+};
+
+// q_host [nq][d] is uploaded; the train rows are either uploaded too (t_host) or already resident (t_dev)
+static int knn2_f32_run(imatch_ctx* ctx, const float* q_host, int64_t nq, const float* t_host, const float* t_dev, int64_t nt, int d,
+                        int32_t* idx, float* dist) {
     if (nq > INT32_MAX / 2 || nt > INT32_MAX / 2) return imatch_set_err(ctx, IMATCH_ESIZE, "set too large");
     if (nq == 0) return IMATCH_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -114,28 +120,87 @@ extern "C" int imatch_knn2_f32(imatch_ctx* ctx, const float* q, int64_t nq, cons
     const int tiles_per_chunk = (int)std::max<int64_t>(1, (n_tiles + n_chunks - 1) / n_chunks);
     n_chunks = (int)std::max<int64_t>(1, (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t bq = up((size_t)nq * d * 4), bt = up((size_t)std::max<int64_t>(nt, 1) * d * 4);
+    const size_t bq = up((size_t)nq * d * 4), bt = t_host ? up((size_t)std::max<int64_t>(nt, 1) * d * 4) : 0;
     const size_t bp = up((size_t)n_chunks * nq * sizeof(kf_top2)), bi = up((size_t)nq * 8), bd = up((size_t)nq * 8);
     int rc = imatch_ws_reserve(ctx, bq + bt + bp + bi + bd);
     if (rc) return rc;
     char* p = (char*)ctx->ws;
     float* qd = (float*)p; p += bq;
-    float* td = (float*)p; p += bt;
+    const float* td = t_host ? (const float*)p : t_dev;
+    p += bt;
     kf_top2* part = (kf_top2*)p; p += bp;
     int* idx_d = (int*)p; p += bi;
     float* dist_d = (float*)p;
-    rc = imatch_hs_reserve(ctx, bq + bt);
+    rc = imatch_hs_reserve(ctx, bq + bt + bi + bd);
     if (rc) return rc;
-    memcpy(ctx->hs, q, (size_t)nq * d * 4);
-    if (nt) memcpy((char*)ctx->hs + bq, t, (size_t)nt * d * 4);
-    HIP_TRY(ctx, hipMemcpyAsync(qd, ctx->hs, bq + (nt ? (size_t)nt * d * 4 : 0), hipMemcpyHostToDevice, ctx->stream));
+    memcpy(ctx->hs, q_host, (size_t)nq * d * 4);
+    if (t_host && nt) memcpy((char*)ctx->hs + bq, t_host, (size_t)nt * d * 4);
+    HIP_TRY(ctx, hipMemcpyAsync(qd, ctx->hs, bq + ((t_host && nt) ? (size_t)nt * d * 4 : 0), hipMemcpyHostToDevice, ctx->stream));
     const size_t lds = std::max((size_t)2 * d * 64 * 4, (size_t)64 * 16 * sizeof(kf_top2));
     hipLaunchKernelGGL(knn2_f32_kernel, dim3(q_tiles, n_chunks), dim3(256), lds, ctx->stream, qd, nq, td, nt, d, tiles_per_chunk, part);
     hipLaunchKernelGGL(knn2_f32_finish_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream, part, n_chunks, nq,
                        idx_d, dist_d);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(idx, idx_d, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(dist, dist_d, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // results come back through the pinned block, behind the uploads
+    char* hres = (char*)ctx->hs + bq + bt;
+    HIP_TRY(ctx, hipMemcpyAsync(hres, idx_d, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(hres + bi, dist_d, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(idx, hres, (size_t)nq * 8);
+    memcpy(dist, hres + bi, (size_t)nq * 8);
     return IMATCH_OK;
 }
+
+extern "C" {
+
+int imatch_knn2_f32(imatch_ctx* ctx, const float* q, int64_t nq, const float* t, int64_t nt, int d, int32_t* idx, float* dist) {
+    if (!ctx || nq < 0 || nt < 0 || d < 1 || d > 128 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    static const float none = 0.f;
+    return knn2_f32_run(ctx, q, nq, nt ? t : &none, nullptr, nt, d, idx, dist);
+}
+
+int imatch_fset_from_host(imatch_ctx* ctx, const float* desc, int64_t n, int d, imatch_fset** out) {
+    if (!ctx || !out || n < 0 || d < 1 || d > 128 || (n > 0 && !desc)) return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    if (n > INT32_MAX / 2) return imatch_set_err(ctx, IMATCH_ESIZE, "set too large");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    imatch_fset* f = (imatch_fset*)calloc(1, sizeof *f);
+    if (!f) return imatch_set_err(ctx, IMATCH_ENOMEM, "host allocation failed");
+    f->ctx = ctx; f->n = n; f->d = d;
+    const size_t bytes = (size_t)std::max<int64_t>(n, 1) * d * 4;
+    f->desc = (float*)imatch_pool_alloc(ctx, bytes);
+    if (!f->desc) {
+        free(f);
+        return imatch_set_err(ctx, IMATCH_ENOMEM, "device block of %zu bytes", bytes);
+    }
+    if (n) {
+        int rc = imatch_hs_reserve(ctx, bytes);
+        if (rc) { imatch_pool_free(ctx, f->desc); free(f); return rc; }
+        memcpy(ctx->hs, desc, bytes);
+        hipError_t e = hipMemcpyAsync(f->desc, ctx->hs, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            imatch_pool_free(ctx, f->desc);
+            free(f);
+            return imatch_set_err(ctx, IMATCH_EHIP, "upload: %s", hipGetErrorString(e));
+        }
+    }
+    *out = f;
+    return IMATCH_OK;
+}
+
+int64_t imatch_fset_count(const imatch_fset* f) { return f ? f->n : 0; }
+
+void imatch_fset_free(imatch_fset* f) {
+    if (!f) return;
+    imatch_pool_free(f->ctx, f->desc);
+    free(f);
+}
+
+int imatch_knn2_fset(imatch_ctx* ctx, const float* q, int64_t nq, const imatch_fset* t, int32_t* idx, float* dist) {
+    if (!ctx || !t || t->ctx != ctx || nq < 0 || (nq > 0 && (!q || !idx || !dist)))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    return knn2_f32_run(ctx, q, nq, nullptr, t->desc, t->n, t->d, idx, dist);
+}
+
+}  // extern "C"

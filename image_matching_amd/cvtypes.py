@@ -123,3 +123,17 @@ class GoodMatches:
 
     def __repr__(self):
         return "GoodMatches(%d)" % len(self)
+
+
+class FloatDescriptors(np.ndarray):
+    """The float32 [K, d] descriptor matrix of the AKAZE path: an ndarray (what cv2 returns) that can carry the
+    handle of its copy in HBM, made the first time the matrix serves as the train side of find_matches; the ROI's
+    descriptors are matched against for up to 11 frames (position_finder.py:232-240) and travel once."""
+
+    def __new__(cls, a):
+        obj = np.ascontiguousarray(a, dtype=np.float32).view(cls)
+        obj.fset = None
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.fset = None      # slices and copies are new matrices

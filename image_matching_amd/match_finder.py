@@ -21,7 +21,7 @@ import numpy as np
 
 from . import draw
 from ._lib import AkazeParams, SiftParams
-from .cvtypes import DeviceDescriptors, GoodMatches, KeyPoints
+from .cvtypes import DeviceDescriptors, FloatDescriptors, GoodMatches, KeyPoints
 from .geodetic_conv import GeodeticConvert
 from .params import get_param, get_param_or_default
 from .utils import default_context, isConvex, line_intersection, resize_img
@@ -168,7 +168,7 @@ class match_finder():
         if self.detector == "akaze":
             rec, desc, out = self.ctx.akaze_extract(img, AkazeParams(self.akaze_threshold, self.akaze_octaves,
                                                                      self.akaze_layers, clahe=True), image=True)
-            return KeyPoints(rec), desc, out
+            return KeyPoints(rec), FloatDescriptors(desc), out
         f = self.ctx.sift_extract(img, self.sift_params(clahe=True))
         kp = KeyPoints(f.download(descriptors=False)[0])
         return kp, DeviceDescriptors(f), f.image(img.shape[0], img.shape[1])
@@ -176,7 +176,12 @@ class match_finder():
     def knn_match(self, query_dp, train_dp):
         """knnMatch(query, train, k=2) -> (idx int32 [Q,2], dist f32 [Q,2]); (-1, inf) where missing."""
         if not hasattr(query_dp, "features") and np.ndim(query_dp) == 2 and np.shape(query_dp)[1] != 128:
-            return self.ctx.knn2_f32(query_dp, train_dp)      # float descriptors (AKAZE's 64-float M-SURF)
+            # float descriptors (AKAZE's 64-float M-SURF); a train matrix made by find_kp_dp is uploaded once
+            if isinstance(train_dp, FloatDescriptors) and len(train_dp) > 0:
+                if train_dp.fset is None or train_dp.fset.ctx is not self.ctx or train_dp.fset._h is None:
+                    train_dp.fset = self.ctx.fset(train_dp)
+                return self.ctx.knn2_f32(query_dp, train_dp.fset)
+            return self.ctx.knn2_f32(query_dp, train_dp)
         return self.ctx.knn2(_features_of(self.ctx, query_dp), _features_of(self.ctx, train_dp))
 
     def find_matches(self, roi, cadr):  # roi, cadr

@@ -196,6 +196,14 @@ int imatch_knn2_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
  * to the lower train index. Host pointers; q is [nq][d], t is [nt][d]. */
 int imatch_knn2_f32(imatch_ctx* ctx, const float* q, int64_t nq, const float* t, int64_t nt, int d, int32_t* idx,
                     float* dist);
+/* A float descriptor set kept in HBM (what cv2.cuda_GpuMat(roi.dp) is for one call, MF:188, kept across calls: the
+ * reference matches every frame against the same ROI descriptors for up to 11 frames, PF:232-240), and the same query
+ * against it: only the frame's descriptors travel. A set belongs to the context it was made on. */
+typedef struct imatch_fset imatch_fset;
+int imatch_fset_from_host(imatch_ctx* ctx, const float* desc, int64_t n, int d, imatch_fset** out);
+int64_t imatch_fset_count(const imatch_fset* f);
+void imatch_fset_free(imatch_fset* f);
+int imatch_knn2_fset(imatch_ctx* ctx, const float* q, int64_t nq, const imatch_fset* t, int32_t* idx, float* dist);
 /* Merge step after the all-gather of per-shard top-2 (no reference counterpart: the reference is
  * single-process). in4_dev is int32 [n_lists][Q][4]; picks the two smallest by
  * (ssd, idx) lexicographic order into out4_dev [Q][4]. */

@@ -22,6 +22,22 @@ def test_bit_exact(ctx, nq, nt, d):
     assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
 
 
+def test_resident_train_set(ctx):
+    """imatch_fset_from_host + imatch_knn2_fset: the train rows travel once; results equal the uploading call's."""
+    t = _unit(7000, 64, 3)
+    fs = ctx.fset(t)
+    assert len(fs) == 7000
+    for seed, nq in ((1, 300), (2, 1), (3, 2049)):     # a larger query set after a smaller one: the workspace regrows
+        q = _unit(nq, 64, seed)
+        gi, gd = ctx.knn2_f32(q, fs)
+        wi, wd = oracle.knn2(q, t)
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+    fs.free()
+    empty = ctx.fset(np.zeros((0, 64), np.float32))
+    gi, gd = ctx.knn2_f32(_unit(5, 64, 9), empty)
+    assert (gi == -1).all() and np.isinf(gd).all()
+
+
 def test_empty_and_ties(ctx):
     q = _unit(10, 64, 1)
     gi, gd = ctx.knn2_f32(q, np.zeros((0, 64), np.float32))
