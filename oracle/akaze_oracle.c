@@ -31,6 +31,10 @@
  *     table weights, angles sorted into 42 slices, the 7-slice window with the largest summed vector.
  *  A7 descriptor (M-SURF 64): 4 x 4 subregions of 9 x 9 samples at step `scale` on the rotated 24-scale grid, bilinear
  *     Lx, Ly, Gaussian 2.5 scale weight per sample and 1.5 per subregion, (sum dx, sum dy, sum |dx|, sum |dy|), unit norm.
+ * Points where this restatement chose without being able to check (no OpenCV here): the cross-level passes search with the
+ * scanning level's sigma_size (not multiplied by the octave ratio); KeyPoint.angle is kept in degrees and converted in the
+ * descriptor; the 2 x 2 box of the octave step adds in the vector path's order ((a + b) + (c + d)); Lx / Ly reach the
+ * orientation and the descriptor unscaled (a per-level factor would cancel in both).
  * Where OpenCV's float order depends on its build (SIMD width, FMA) one order is fixed here: filters are ascending-tap
  * fmaf chains (as sift_oracle.c), everything else is the source's expression order without contraction. fastAtan2 and
  * OpenCV's exp are libm's here. A new octave is resize(INTER_AREA) of the last level (oracle_resize_area_f32).
