@@ -15,7 +15,18 @@ timeout -k 10 600 python3 -u "$root/bench.py" > "$out/bench.json" 2> "$out/bench
 step kernel-trace bench
 timeout -k 10 400 rocprofv3 --kernel-trace -d "$out/kt_bench" -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline \
     > "$out/kt_bench.json" 2> "$out/kt_bench.err" || exit 1
-python3 "$root/tools/rocpd_stats.py" "$out"/kt_bench/*/*_results.db "$out/bench_kernel_stats.md" > /dev/null || exit 1
+python3 "$root/tools/rocpd_stats.py" "$out"/kt_bench/*/*_results.db "$out/bench_kernel_stats.body.md" > /dev/null || exit 1
+# header: the tracer's cost on the dominant kernel, from the two JSON lines
+python3 - "$out" <<'PY' || exit 1
+import json, sys
+out = sys.argv[1]
+ms = lambda f: json.loads(open(out + "/" + f).read().strip().splitlines()[-1])["roofline"]["launch_ms"]
+head = ("rocprofv3 --kernel-trace of `bench.py --steps 5 --warmup 2 --no-cpu-baseline` (tools/collect_profiles.sh). Compare the per-shape kNN rows\n"
+        "at the end with roofline.launch_ms of the same run (%.2f ms) and of the un-profiled bench beside it (%.2f ms): the difference is the\n"
+        "tracer's cost on this kernel.\n\n" % (ms("kt_bench.json"), ms("bench.json")))
+open(out + "/bench_kernel_stats.md", "w").write(head + open(out + "/bench_kernel_stats.body.md").read())
+PY
+rm -f "$out/bench_kernel_stats.body.md"
 
 step kernel-trace map extraction
 timeout -k 10 400 rocprofv3 --kernel-trace -d "$out/kt_map" -- python3 "$root/tools/extract_profile.py" 8192 3 \
