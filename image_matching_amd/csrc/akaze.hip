@@ -642,13 +642,21 @@ ak_orient_kernel(float* __restrict__ kp, int n, ak_levels_dev L) {
         bin[w][r] = (unsigned char)b;
     }
     __syncthreads();
-    if (lane == 0 && live) {   // counting sort by slice, stable in the sample index
-        int cnt[43];
-        for (int b = 0; b <= 42; ++b) cnt[b] = 0;
-        for (int s = 0; s < 109; ++s) cnt[bin[w][s] + 1]++;
-        for (int b = 0; b < 42; ++b) cnt[b + 1] += cnt[b];
-        for (int b = 0; b <= 42; ++b) start[w][b] = (unsigned char)cnt[b];
-        for (int s = 0; s < 109; ++s) order[w][cnt[bin[w][s]]++] = (unsigned char)s;
+    if (live) {   // counting sort by slice, stable in the sample index -- every lane ranks its own samples (no serial pass)
+        for (int s = lane; s < 109; s += 64) {
+            const int b = bin[w][s];
+            int r = 0;
+            for (int j = 0; j < 109; ++j) {
+                const int bj = bin[w][j];
+                r += (bj < b) || (bj == b && j < s);
+            }
+            order[w][r] = (unsigned char)s;
+        }
+        if (lane < 43) {
+            int c = 0;
+            for (int j = 0; j < 109; ++j) c += bin[w][j] < lane;
+            start[w][lane] = (unsigned char)c;
+        }
     }
     __syncthreads();
     // lane sn sums the window of 7 slices starting at slice sn, in the oracle's order
