@@ -464,13 +464,31 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
         }
     }
 
-    // one partial list per (chunk, row quarter)
-    const int64_t list = (int64_t)chunk * 4 + q;
+    // The four lanes that hold a query's lists (row quarters, disjoint rows) merge them by two exchange rounds, in
+    // (value, train index) order -- the values are exact integers, so equal values are true ties and the lower index
+    // ranks first, as the ascending scan would have it; one partial list per chunk is written.
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const int64_t o = list * Qpad + qrow0 + qb * 16 + r;
-        pb[o] = make_float2(b1[qb], b2[qb]);
-        pi[o] = make_int2(i1[qb], i2[qb]);
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float ob1 = __shfl_xor(b1[qb], off), ob2 = __shfl_xor(b2[qb], off);
+            const int oi1 = __shfl_xor(i1[qb], off), oi2 = __shfl_xor(i2[qb], off);
+            const bool o_first = ob1 < b1[qb] || (ob1 == b1[qb] && (unsigned)oi1 < (unsigned)i1[qb]);
+            // the runner-up: the loser of the first comparison against the winner's own second
+            const float w1 = o_first ? ob1 : b1[qb], l1 = o_first ? b1[qb] : ob1, w2 = o_first ? ob2 : b2[qb];
+            const int wi1 = o_first ? oi1 : i1[qb], li1 = o_first ? i1[qb] : oi1, wi2 = o_first ? oi2 : i2[qb];
+            const bool l_second = l1 < w2 || (l1 == w2 && (unsigned)li1 < (unsigned)wi2);
+            b1[qb] = w1; i1[qb] = wi1;
+            b2[qb] = l_second ? l1 : w2; i2[qb] = l_second ? li1 : wi2;
+        }
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int64_t o = (int64_t)chunk * Qpad + qrow0 + qb * 16 + r;
+            pb[o] = make_float2(b1[qb], b2[qb]);
+            pi[o] = make_int2(i1[qb], i2[qb]);
+        }
     }
 }
 
@@ -756,7 +774,7 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     if (nChunks > nStages / 4) nChunks = (nStages / 4 / 8) * 8;
     if (nChunks < 8) nChunks = 8;
     if (const char* e = getenv("IMATCH_KNN_CHUNKS")) nChunks = std::max(8, atoi(e) / 8 * 8);  // tuning override
-    const int64_t nLists = (int64_t)nChunks * (use16 ? 4 : 2);
+    const int64_t nLists = (int64_t)nChunks * (use16 ? 1 : 2);   // the 16x16x32 kernel merges its four row quarters itself
     const size_t pbytes = (size_t)nLists * Qpad * 8;
     const size_t gbytes = ((size_t)Qpad * 12 + 255) & ~(size_t)255;   // three bounds per query
     int rc = imatch_ws_reserve(ctx, 2 * pbytes + gbytes);
