@@ -203,10 +203,60 @@ resize_area_fast_kernel(const uint8_t* __restrict__ src, int stride, uint8_t* __
     dst[(size_t)dy * dcols + dx] = (isx == 2 && isy == 2) ? (uint8_t)((sum + 2) >> 2) : sat_u8((float)sum * scale);
 }
 
+// INTER_AREA with an enlarged axis: resize.cpp's bilinear kernel with the area_mode coefficients, 8-bit fixed point
+// (weights of 11 bits, int horizontal sums, the vertical pass's two-stage shifts). One thread per output pixel.
+__device__ __forceinline__ void area_lin_coef(int d, double scale, double inv_scale, int ssize, bool is_x, int& s, int& a0, int& a1,
+                                              bool& edge) {
+    s = (int)floor(d * scale);
+    float f = (float)((d + 1) - (s + 1) * inv_scale);
+    f = f <= 0 ? 0.f : f - floorf(f);
+    edge = false;
+    if (is_x) {
+        if (s < 0) { f = 0; s = 0; }
+        if (s + 1 >= ssize) {
+            edge = true;
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+    }
+    a0 = __float2int_rn((1.f - f) * 2048.f);
+    a1 = __float2int_rn(f * 2048.f);
+}
+
+__global__ void __launch_bounds__(256)
+resize_area_enlarge_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, uint8_t* __restrict__ dst, int drows,
+                           int dcols, double scale_x, double scale_y, double inv_x, double inv_y) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dcols || dy >= drows) return;
+    int sx, a0, a1, sy, b0, b1;
+    bool ex, ey;
+    area_lin_coef(dx, scale_x, inv_x, cols, true, sx, a0, a1, ex);
+    area_lin_coef(dy, scale_y, inv_y, rows, false, sy, b0, b1, ey);
+    const int y0 = min(max(sy, 0), rows - 1), y1 = min(max(sy + 1, 0), rows - 1);
+    const uint8_t* S0 = src + (size_t)y0 * stride;
+    const uint8_t* S1 = src + (size_t)y1 * stride;
+    int r0, r1;
+    if (!ex) {
+        r0 = S0[sx] * a0 + S0[sx + 1] * a1;
+        r1 = S1[sx] * a0 + S1[sx + 1] * a1;
+    } else {
+        r0 = S0[sx] * 2048;
+        r1 = S1[sx] * 2048;
+    }
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    dst[(size_t)dy * dcols + dx] = (uint8_t)min(max(v, 0), 255);
+}
+
 int imatch_resize_area_dev(imatch_ctx* ctx, const uint8_t* src_dev, int h, int w, int stride, uint8_t* dst_dev, int dh,
                            int dw) {
     const double inv_x = (double)dw / w, inv_y = (double)dh / h;
     const double sx = 1. / inv_x, sy = 1. / inv_y;
+    if (dh > h || dw > w) {
+        hipLaunchKernelGGL(resize_area_enlarge_kernel, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(256), 0, ctx->stream, src_dev, h, w,
+                           stride, dst_dev, dh, dw, sx, sy, inv_x, inv_y);
+        HIP_TRY(ctx, hipGetLastError());
+        return IMATCH_OK;
+    }
     const int isx = (int)lrint(sx), isy = (int)lrint(sy);
     const dim3 grid((dw + 63) / 64, (dh + 3) / 4);
     if (fabs(sx - isx) < 2.220446049250313e-16 && fabs(sy - isy) < 2.220446049250313e-16)
@@ -247,8 +297,6 @@ int imatch_clahe(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, 
 int imatch_resize_area(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, uint8_t* out, int dh, int dw) {
     if (!ctx || !img || !out || h <= 0 || w <= 0 || stride < w || dh <= 0 || dw <= 0)
         return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
-    if (dh > h || dw > w)
-        return imatch_set_err(ctx, IMATCH_ESIZE, "INTER_AREA enlargement (%dx%d -> %dx%d) is not implemented", w, h, dw, dh);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t px = ((size_t)h * w + 255) & ~(size_t)255;
     int rc = imatch_ws_reserve(ctx, px + (size_t)dh * dw);

@@ -75,7 +75,8 @@ void imatch_features_free(imatch_features* f);
 int imatch_clahe(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride, double clip_limit,
                  int tiles_x, int tiles_y, uint8_t* out);
 /* Replaces cv2.resize(img, (dw, dh), interpolation=cv2.INTER_AREA) as utils.resize_img calls it
- * (utils.py:17-22; callers MF:165-175,308-311). Shrinking only (dh <= h, dw <= w). */
+ * (utils.py:17-22; callers MF:165-175,308-311). An enlarged axis takes OpenCV's bilinear kernel with INTER_AREA's
+ * coefficients, as cv2 does. */
 int imatch_resize_area(imatch_ctx* ctx, const uint8_t* img, int h, int w, int stride,
                        uint8_t* out, int dh, int dw);
 

@@ -127,13 +127,13 @@ def clahe(img, clip_limit=30.0, tiles=(8, 8)):
 
 
 def resize_area(img, dsize):
-    """cv2.resize(img, dsize=(width, height), interpolation=cv2.INTER_AREA), shrink only."""
+    """cv2.resize(img, dsize=(width, height), interpolation=cv2.INTER_AREA)."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     dw, dh = int(dsize[0]), int(dsize[1])
     out = np.empty((dh, dw), np.uint8)
     rc = lib().oracle_resize_area(_p(img, _u8p), img.shape[0], img.shape[1], _p(out, _u8p), dh, dw)
     if rc != 0:
-        raise ValueError("oracle.resize_area restates shrinking only")
+        raise ValueError("oracle.resize_area: empty destination")
     return out
 
 

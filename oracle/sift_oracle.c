@@ -156,9 +156,73 @@ static int area_tab(int ssize, int dsize, double scale, dec_alpha* tab) {
     return k;
 }
 
-/* returns 0, or -1 when the call is not a shrink in both directions (not restated) */
+/* resize(INTER_AREA) when an axis is enlarged: resize.cpp switches to the bilinear kernel with INTER_AREA's own
+ * coefficients (area_mode): s = cvFloor(d * scale), f = (d + 1) - (s + 1) / scale clipped to [0, 1); 8-bit images take the
+ * fixed-point path: weights saturate_cast<short>(w * 2048), the horizontal pass keeps int sums (a source column beyond the
+ * last one contributes S[last] * 2048), the vertical pass is ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2. */
+static void area_lin_coef(int d, double scale, double inv_scale, int ssize, int is_x, int* s_out, short* a0, short* a1, int* edge) {
+    int s = (int)floor(d * scale);
+    float f = (float)((d + 1) - (s + 1) * inv_scale);
+    f = f <= 0 ? 0.f : f - (float)cv_floor(f);
+    *edge = 0;
+    if (is_x) {
+        if (s < 0) { f = 0; s = 0; }
+        if (s + 1 >= ssize) {
+            *edge = 1;                       /* xmax: the pass reads S[s] * ONE */
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+    }
+    *s_out = s;
+    *a0 = (short)lrintf((1.f - f) * 2048.f);
+    *a1 = (short)lrintf(f * 2048.f);
+}
+
+static void resize_area_enlarge(const uint8_t* src, int rows, int cols, uint8_t* dst, int drows, int dcols) {
+    const double inv_x = (double)dcols / cols, inv_y = (double)drows / rows;
+    const double sx = 1. / inv_x, sy = 1. / inv_y;
+    int* xo = (int*)malloc(sizeof(int) * dcols);
+    short* xa = (short*)malloc(sizeof(short) * 2 * dcols);
+    int* xe = (int*)malloc(sizeof(int) * dcols);
+    /* xmax is the FIRST column whose source pair leaves the image; every column from there on takes the edge form */
+    int xmax = dcols;
+    for (int dx = 0; dx < dcols; ++dx) {
+        area_lin_coef(dx, sx, inv_x, cols, 1, &xo[dx], &xa[2 * dx], &xa[2 * dx + 1], &xe[dx]);
+        if (xe[dx] && dx < xmax) xmax = dx;
+    }
+    int* r0 = (int*)malloc(sizeof(int) * dcols);
+    int* r1 = (int*)malloc(sizeof(int) * dcols);
+    for (int dy = 0; dy < drows; ++dy) {
+        int s, e;
+        short b0, b1;
+        area_lin_coef(dy, sy, inv_y, rows, 0, &s, &b0, &b1, &e);
+        const int y0 = s < 0 ? 0 : (s < rows ? s : rows - 1), y1 = s + 1 < 0 ? 0 : (s + 1 < rows ? s + 1 : rows - 1);
+        const uint8_t* S0 = src + (size_t)y0 * cols;
+        const uint8_t* S1 = src + (size_t)y1 * cols;
+        for (int dx = 0; dx < dcols; ++dx) {
+            if (dx < xmax) {
+                r0[dx] = S0[xo[dx]] * xa[2 * dx] + S0[xo[dx] + 1] * xa[2 * dx + 1];
+                r1[dx] = S1[xo[dx]] * xa[2 * dx] + S1[xo[dx] + 1] * xa[2 * dx + 1];
+            } else {
+                r0[dx] = S0[xo[dx]] * 2048;
+                r1[dx] = S1[xo[dx]] * 2048;
+            }
+        }
+        uint8_t* D = dst + (size_t)dy * dcols;
+        for (int dx = 0; dx < dcols; ++dx) {
+            const int v = (((b0 * (r0[dx] >> 4)) >> 16) + ((b1 * (r1[dx] >> 4)) >> 16) + 2) >> 2;
+            D[dx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+    free(xo); free(xa); free(xe); free(r0); free(r1);
+}
+
+/* returns 0, or -1 for an empty destination */
 int oracle_resize_area(const uint8_t* src, int rows, int cols, uint8_t* dst, int drows, int dcols) {
-    if (drows <= 0 || dcols <= 0 || drows > rows || dcols > cols) return -1;
+    if (drows <= 0 || dcols <= 0) return -1;
+    if (drows > rows || dcols > cols) {   /* scale_x < 1 or scale_y < 1: the area_mode bilinear path */
+        resize_area_enlarge(src, rows, cols, dst, drows, dcols);
+        return 0;
+    }
     /* resize(): inv_scale = dsize/ssize; scale = 1./inv_scale; iscale = saturate_cast<int>(scale) */
     const double sx = 1. / ((double)dcols / cols), sy = 1. / ((double)drows / rows);
     const int isx = cv_round_d(sx), isy = cv_round_d(sy);

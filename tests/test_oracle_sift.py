@@ -101,3 +101,37 @@ def test_whole_chain_recovers_planted_homography():
     pa, pb = c @ He.T, c @ H.T
     # a few dozen inliers on a 320x240 frame: statistical error of the estimate, not a parity bar
     assert np.abs(pa[:, :2] / pa[:, 2:] - pb[:, :2] / pb[:, 2:]).max() < 3.0
+
+
+def test_resize_area_enlargement():
+    """INTER_AREA with an enlarged axis is OpenCV's bilinear kernel with area coefficients: an integer factor replicates
+    pixels (f = 0 everywhere), a constant image stays constant, values stay inside the source's range and the result
+    follows the float statement of the same coefficients within the fixed-point rounding."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    twice = oracle.resize_area(img, (106, 74))
+    assert np.array_equal(twice, np.repeat(np.repeat(img, 2, axis=0), 2, axis=1))
+    assert (oracle.resize_area(np.full((9, 9), 77, np.uint8), (20, 31)) == 77).all()
+    dw, dh = 71, 50
+    out = oracle.resize_area(img, (dw, dh)).astype(np.float64)
+
+    def coef(d, n_src, n_dst):
+        scale, inv = n_src / n_dst, n_dst / n_src
+        s = int(np.floor(d * scale))
+        f = (d + 1) - (s + 1) * inv
+        f = 0.0 if f <= 0 else f - np.floor(f)
+        return s, f
+    want = np.zeros((dh, dw))
+    for dy in range(dh):
+        sy, fy = coef(dy, 37, dh)
+        y1 = min(sy + 1, 36)
+        for dx in range(dw):
+            sx, fx = coef(dx, 53, dw)
+            if sx >= 52:
+                sx, fx = 52, 0.0
+            x1 = min(sx + 1, 52)
+            top = img[sy, sx] * (1 - fx) + img[sy, x1] * fx
+            bot = img[y1, sx] * (1 - fx) + img[y1, x1] * fx
+            want[dy, dx] = top * (1 - fy) + bot * fy
+    assert np.abs(out - want).max() <= 1.0
+    assert out.min() >= img.min() and out.max() <= img.max()

@@ -48,9 +48,16 @@ def test_resize_area_bit_exact(ctx, small_map, shape, dsize):
     assert np.array_equal(got, want), int((got != want).sum())
 
 
-def test_resize_enlarge_is_an_error(ctx, small_map):
-    with pytest.raises(im.ImatchError):
-        ctx.resize_area(small_map[:100, :100], (200, 200))
+@pytest.mark.parametrize("shape,dsize", [((100, 100), (200, 200)), ((97, 131), (140, 103)), ((240, 320), (640, 480)),
+                                         ((50, 70), (233, 51)), ((60, 80), (79, 121)), ((1, 1), (5, 3))])
+def test_resize_enlarge_bit_exact(ctx, small_map, shape, dsize):
+    """An enlarged axis: cv2.resize(INTER_AREA) runs its bilinear kernel with the area coefficients (a frame narrower
+    than image_size_sift makes rescale_cadr enlarge, match_finder.py:171-175)."""
+    img = np.ascontiguousarray(small_map[:shape[0], :shape[1]])
+    got = ctx.resize_area(img, dsize)
+    want = oracle.resize_area(img, dsize)
+    assert got.shape == want.shape == (dsize[1], dsize[0])
+    assert np.array_equal(got, want), int((got != want).sum())
 
 
 @pytest.mark.parametrize("shape", [(240, 320), (201, 333), (64, 96)])
