@@ -446,6 +446,18 @@ class Context:
                                                  _ptr(idx, c_i32p), _ptr(dist, c_f32p)))
         return idx, dist
 
+    def akaze_extract_dev(self, img_ptr, h, w, stride, params=None):
+        """The same for a u8 image already in device memory (a torch tensor's data_ptr()) -> (kp, desc)."""
+        params = params or AkazeParams()
+        n = c_i64()
+        with self.lock:
+            self._check(self.lib.imatch_akaze_extract_dev(self._h, c_vp(img_ptr), int(h), int(w), int(stride),
+                                                          ctypes.byref(params), ctypes.byref(n)))
+            kp = np.empty((n.value, 7), np.float32)
+            desc = np.empty((n.value, 64), np.float32)
+            self._check(self.lib.imatch_akaze_download(self._h, _ptr(kp, c_f32p), _ptr(desc, c_f32p)))
+        return kp, desc
+
     def akaze_debug_layer(self, kind, level):
         """Test hook: plane `kind` (0 Lt, 1 Lsmooth, 2 Lx, 3 Ly, 4 Ldet, 5 contrast factor) of evolution level `level`."""
         r, c = ctypes.c_int(), ctypes.c_int()

@@ -84,6 +84,20 @@ def test_clahe_first_as_find_kp_dp(ctx):
     assert np.array_equal(kp[:, [0, 1, 2, 4, 5, 6]], want.kp[:, [0, 1, 2, 4, 5, 6]])
 
 
+def test_device_image_and_strided_rows(ctx):
+    """imatch_akaze_extract_dev: the frame hand-off from a torch tensor, rows further apart than the width."""
+    import torch
+    img = np.ascontiguousarray(synth.synth_map(512, seed=8)[:240, :320])
+    want_kp, want_desc = ctx.akaze_extract(img, AkazeParams())
+    wide = torch.zeros((240, 384), dtype=torch.uint8, device="cuda:0")
+    wide[:, :320] = torch.from_numpy(img).to("cuda:0")
+    torch.cuda.synchronize()
+    for clahe in (True, False):
+        kp, desc = ctx.akaze_extract_dev(wide.data_ptr(), 240, 320, 384, AkazeParams(clahe=clahe))
+        ref_kp, ref_desc = (want_kp, want_desc) if clahe else ctx.akaze_extract(img, AkazeParams(clahe=False))
+        assert np.array_equal(kp, ref_kp) and np.array_equal(desc, ref_desc)
+
+
 def test_golden_fixture(ctx):
     g = np.load(os.path.join(ROOT, "tests", "golden", "akaze_small.npz"))
     kp, desc = ctx.akaze_extract(g["img"], AkazeParams(clahe=False))
