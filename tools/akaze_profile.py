@@ -1,5 +1,5 @@
-"""AKAZE path timing on one MI355X: extraction of a 640x480 frame and of a 2048^2 crop, the float kNN between them, and
-the oracle beside it. Usage: python tools/akaze_profile.py [reps]"""
+"""AKAZE path timing on one MI355X: extraction of a 640x480 frame and of a 2048^2 crop, the float kNN between them.
+Usage: python tools/akaze_profile.py [reps]"""
 import os
 import sys
 import time
@@ -34,14 +34,6 @@ def main():
         ctx.knn2_f32(fd, md)
     ms = (time.perf_counter() - t) / reps * 1e3
     print("knn2_f32 %d x %d x 64: %.3f ms (uploads included)" % (len(fd), len(md), ms), flush=True)
-    if "--oracle" in sys.argv:
-        import oracle
-        t = time.perf_counter()
-        oracle.akaze(oracle.clahe(frame, 30.0, (8, 8)))
-        print("oracle frame extraction (OpenMP): %.1f ms" % ((time.perf_counter() - t) * 1e3))
-        t = time.perf_counter()
-        oracle.knn2(fd, md)
-        print("oracle kNN: %.1f ms" % ((time.perf_counter() - t) * 1e3))
 
 
 main()
