@@ -98,6 +98,13 @@ def test_device_image_and_strided_rows(ctx):
         assert np.array_equal(kp, ref_kp) and np.array_equal(desc, ref_desc)
 
 
+def test_whole_map_8192(ctx):
+    """BASELINE.json's 8192 x 8192 map through the AKAZE detector in one call (calculate_db's extraction with
+    detector="akaze"): ~1.6e5 keypoints, the same as the oracle's to the bars above."""
+    kp, _ = _compare(ctx, synth.synth_map(8192, seed=21), planes=False)
+    assert len(kp) > 100000
+
+
 def test_golden_fixture(ctx):
     g = np.load(os.path.join(ROOT, "tests", "golden", "akaze_small.npz"))
     kp, desc = ctx.akaze_extract(g["img"], AkazeParams(clahe=False))
