@@ -53,6 +53,26 @@ def test_empty_and_ties(ctx):
     assert tuple(gi[10]) == (7, 123) and tuple(gi[3]) == (20, 300) and gd[3, 0] == 0
 
 
+def test_large_train_set_properties(ctx):
+    """A million train rows (six whole-map AKAZE extractions): planted exact duplicates come back as (lower index, higher
+    index) at distance 0, and a sample of the queries is compared with the oracle in full."""
+    nt, nq = 1 << 20, 2048
+    t = _unit(nt, 64, 11)
+    rows = np.random.default_rng(12).choice(nt - 60000, nq // 2, replace=False)
+    t[rows + 54321] = t[rows]
+    q = np.vstack([t[rows], _unit(nq // 2, 64, 13)])
+    gi, gd = ctx.knn2_f32(q, t)
+    first = np.minimum(rows, rows + 54321)
+    # a planted row may itself have been overwritten by another plant: judge by content, not by index
+    assert (gd[:nq // 2] == 0).all()
+    assert np.array_equal(t[gi[:nq // 2, 0]], q[:nq // 2]) and np.array_equal(t[gi[:nq // 2, 1]], q[:nq // 2])
+    assert (gi[:nq // 2, 0] < gi[:nq // 2, 1]).all() and (gi[:nq // 2, 0] <= first).all()
+    assert (gd[:, 0] <= gd[:, 1]).all()
+    pick = np.r_[0:8, nq - 8:nq]
+    wi, wd = oracle.knn2(q[pick], t)
+    assert np.array_equal(gi[pick], wi) and np.array_equal(gd[pick], wd)
+
+
 def test_akaze_chain_through_the_facade(ctx):
     """find_kp_dp -> find_matches -> find_keypoints_transform with detector='akaze' recovers a planted homography."""
     from image_matching_amd import synth
