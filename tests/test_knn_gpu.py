@@ -42,6 +42,20 @@ def test_ragged_sizes(ctx, nq, nt):
     _check(ctx, q, t)
 
 
+@pytest.mark.parametrize("nq,nt", [(513, 129), (6144, 16384), (6145, 30000), (8192, 16385), (7000, 100001), (12000, 50000),
+                                   (600, 127), (5000, 1 << 17)])
+def test_kernel_path_boundaries_with_ties(ctx, nq, nt):
+    """Sizes either side of the launcher's switches (512 / 6144 queries, 128-row stages, 16 k-row chunks) with a fifth of
+    the train rows copied from other rows: equal distances across chunk and row-quarter boundaries, lowest index first."""
+    t = synth.synth_descriptors(nt, seed=nt)
+    rng = np.random.default_rng(nq)
+    src = rng.integers(0, nt, nt // 5)
+    dst = rng.integers(0, nt, nt // 5)
+    t[dst] = t[src]
+    q, _, _ = synth.synth_queries(t, nq, seed=nq, dup_frac=0.3)
+    _check(ctx, q, t)
+
+
 def test_extreme_values_exact(ctx):
     """All-255 queries vs (almost) all-0 rows: ssd = 128*255^2 = 8 323 200, the largest value the path can see."""
     t = np.zeros((300, 128), np.uint8)
