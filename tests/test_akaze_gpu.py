@@ -49,6 +49,23 @@ def test_other_sizes(ctx):
         _compare(ctx, np.ascontiguousarray(m[:h, :w]), planes=(h < 500))
 
 
+def test_awkward_sizes(ctx):
+    """Either side of the single-workgroup level's 19 200-pixel limit, thin strips, odd sizes in both axes; on the small ones
+    a noise crop as well (many keypoints per level)."""
+    m = synth.synth_map(1536, seed=31)
+    rng = np.random.default_rng(4)
+    noise = rng.integers(0, 256, (700, 700), dtype=np.uint8)
+    total = 0
+    for h, w in [(120, 160), (120, 161), (121, 160), (40, 600), (600, 40), (277, 139), (139, 277), (64, 64), (65, 65), (320, 240),
+                 (553, 555), (97, 131), (200, 96), (768, 1024), (1100, 900)]:
+        y0, x0 = int(rng.integers(0, 1536 - h)), int(rng.integers(0, 1536 - w))
+        _compare(ctx, np.ascontiguousarray(m[y0:y0 + h, x0:x0 + w]), planes=(h * w < 400000))
+        if h * w < 50000:
+            kp, _ = _compare(ctx, np.ascontiguousarray(noise[:h, :w]), planes=True, threshold=1e-5)
+            total += len(kp)
+    assert total > 200
+
+
 def test_other_parameters(ctx):
     """Other thresholds, octave and sublevel counts than the reference's call (sigma_size reaches 5 with 3 sublevels... the
     FED cycles and borders change with them)."""
