@@ -58,6 +58,7 @@ def cpu_baseline(frames, map_desc_sample, n_map, map_xy_sample, ratio, threads):
     t_ext = t_knn_s = t_h = 0.0
     pairs = 0
     done = 0
+    kept = []
     t_start = time.perf_counter()
     for frame in frames:
         t0 = time.perf_counter()
@@ -66,9 +67,11 @@ def cpu_baseline(frames, map_desc_sample, n_map, map_xy_sample, ratio, threads):
         idx, dist = oracle.knn2(res.desc.astype(np.uint8), map_desc_sample, threads=threads)
         t2 = time.perf_counter()
         gq, gt, _ = oracle.ratio(idx, dist, ratio)
+        H = None
         if len(gq) >= 4:
-            oracle.homography(res.kp[gq, :2], map_xy_sample[gt], 0.1, seed=0)
+            H, _ = oracle.homography(res.kp[gq, :2], map_xy_sample[gt], 0.1, seed=0)
         t3 = time.perf_counter()
+        kept.append((res.kp, res.desc, idx, dist, gq, gt, H))
         t_ext += t1 - t0; t_knn_s += t2 - t1; t_h += t3 - t2
         pairs += len(res.desc) * len(map_desc_sample)
         done += 1
@@ -83,7 +86,56 @@ def cpu_baseline(frames, map_desc_sample, n_map, map_xy_sample, ratio, threads):
                   % (done, t_ext + t_knn_s + t_h, threads, t_ext / done, len(map_desc_sample), t_knn_s / done,
                      "" if scale == 1 else " (scaled x%.1f to %d)" % (scale, n_map), t_h / done),
         "knn_gdist_per_s": pairs / t_knn_s / 1e9,
-    }
+    }, kept
+
+
+def parity_block(ctx, params, frames, truth_H, kept, f_map, map_xy, ratio):
+    """SURVEY 8(d) "parity checks run with every measurement": the frames the CPU baseline leg just ran through the
+    oracle, run through the HIP entry points and compared with what the oracle gave (the oracle is the checker here;
+    nothing below is timed)."""
+    try:
+        from scipy.spatial import cKDTree
+        corners = np.array([[0, 0, 1], [639, 0, 1], [639, 479, 1], [0, 479, 1]], np.float64).T
+        centre = np.array([319.5, 239.5, 1.0])
+
+        def proj(H, p):
+            v = H @ p
+            return v[:2] / v[2]
+        kp_hit, kp_n, l2 = 0, 0, []
+        knn_same = ratio_same = True
+        h_err, pos_err = [], []
+        for (okp, odesc, oidx, odist, ogq, ogt, oH), frame, Ht in zip(kept, frames, truth_H):
+            f = ctx.sift_extract(frame, params)
+            gkp, gdesc = f.download()
+            d, j = cKDTree(gkp[:, :2]).query(okp[:, :2])
+            # a location carries one record per orientation peak: pair records by location first, then by angle
+            hit = d < 0.5
+            kp_hit += int(hit.sum())
+            kp_n += len(okp)
+            same = hit & (np.abs((gkp[j, 3] - okp[:, 3] + 180.0) % 360.0 - 180.0) < 1.0)
+            l2.extend(np.linalg.norm(gdesc[j[same]] - odesc[same], axis=1).tolist())
+            # the matcher on the oracle's own descriptors: indices, distances and ratio decisions bit for bit
+            fq = ctx.features(odesc.astype(np.uint8))
+            gidx, gdist = ctx.knn2(fq, f_map)
+            knn_same &= bool(np.array_equal(gidx, oidx) and np.array_equal(gdist, odist))
+            keep = np.nonzero(gdist[:, 0].astype(np.float64) < ratio * gdist[:, 1].astype(np.float64))[0]
+            ratio_same &= bool(np.array_equal(keep, ogq) and np.array_equal(gidx[keep, 0], ogt))
+            fq.free()
+            f.free()
+            if oH is not None and len(ogq) > 10:
+                gH, _ = ctx.homography(okp[ogq, :2], map_xy[ogt], 0.1, seed=0)
+                if gH is not None:
+                    h_err.append(float(max(np.hypot(*(proj(gH, c) - proj(oH, c))) for c in corners.T)))
+                    pos_err.append(float(np.hypot(*(proj(gH, centre) - proj(Ht, centre)))))
+        l2 = np.asarray(l2) if l2 else np.zeros(1)
+        return {"frames": len(kept), "keypoints_within_0.5px": kp_hit / max(kp_n, 1),
+                "descriptor_l2_p99": float(np.percentile(l2, 99)), "descriptor_l2_max": float(l2.max()),
+                "knn_idx_and_dist_bit_exact": knn_same, "ratio_decisions_identical": ratio_same,
+                "homography_corner_px_vs_oracle_max": max(h_err) if h_err else None,
+                "frame_centre_map_px_vs_planted_truth_median": float(np.median(pos_err)) if pos_err else None,
+                "note": "HIP entry points against the CPU oracle on the cpu_baseline leg's frames; after the timed region"}
+    except Exception as e:      # must not take the headline down with it
+        return {"error": repr(e)[:300]}
 
 
 def akaze_extra(ctx, map_img, ratio):
@@ -221,7 +273,9 @@ def main():
     f_local = f_map if map_mode == "replicated" else f_shard
 
     # ---- frames: each rank has its own set, resident in HBM before the timed region
-    frames_h = [synth.synth_frame(map_img, 100 * rank + i, size=(480, 640))[0] for i in range(args.frames)]
+    frames_t = [synth.synth_frame(map_img, 100 * rank + i, size=(480, 640)) for i in range(args.frames)]
+    frames_h = [f for f, _ in frames_t]
+    truth_H = [h for _, h in frames_t]
     frames_d = [torch.from_numpy(f).to(dev) for f in frames_h]
     q_cap = 4096                     # rows per frame in the exchange / result buffers (frames here have ~3000 keypoints)
 
@@ -456,7 +510,9 @@ def main():
             threads = min(16, os.cpu_count() or 1)
             n_s = n_map if n_map <= 300_000 else 100_000
             d_s = f_local.download(keypoints=False)[1][:n_s].astype(np.uint8)
-            out["cpu_baseline"] = cpu_baseline(frames_h[:16], d_s, n_map, map_xy[:n_s], ratio, threads)
+            out["cpu_baseline"], kept = cpu_baseline(frames_h[:16], d_s, n_map, map_xy[:n_s], ratio, threads)
+            if n_s == n_map:    # the oracle matched against the whole map: its lists are comparable as they are
+                out["parity"] = parity_block(ctx, params, frames_h, truth_H, kept, f_local, map_xy, ratio)
         else:
             out["cpu_baseline"] = None
     else:
