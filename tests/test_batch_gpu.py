@@ -58,6 +58,41 @@ def test_batch_of_one_and_ragged_pitch(ctx, scene):
     assert o1.tolist() == [0, offs[1]]
 
 
+def test_full_batch_at_the_bench_shape_and_odd_sizes(ctx, scene):
+    """64 frames of 640 x 480 in one call (bench.py's step), one of them flat (an empty segment in the middle), and a batch
+    of 7 odd-sized images: every image as the single-image call gives it."""
+    m, _ = scene
+    dev = torch.device("cuda", 0)
+    base = [synth.synth_frame(m, 40 + i, size=(480, 640), scale_range=(0.5, 0.6))[0] for i in range(6)]
+    frames = [base[i % 6] for i in range(64)]
+    frames[29] = np.full((480, 640), 93, np.uint8)
+    frames[63] = np.ascontiguousarray(base[2][::-1])
+    stack = torch.from_numpy(np.stack(frames)).to(dev)
+    f, offs = ctx.sift_extract_batch_dev(stack.data_ptr(), 64, 480 * 640, 480, 640, 640)
+    kp, desc = f.download()
+    assert offs[29] == offs[30] and offs[-1] == len(f)
+    singles = {}
+    for b in (0, 1, 5, 28, 29, 30, 31, 32, 62, 63):
+        key = b % 6 if b not in (29, 63) else b
+        if key not in singles:
+            one = ctx.sift_extract(frames[b])
+            singles[key] = one.download()
+            one.free()
+        kp1, desc1 = singles[key]
+        assert np.array_equal(kp[offs[b]:offs[b + 1]], kp1) and np.array_equal(desc[offs[b]:offs[b + 1]], desc1), b
+    f.free()
+    odd = [np.ascontiguousarray(m[10 * i:10 * i + 243, 7 * i:7 * i + 325]) for i in range(7)]
+    stack = torch.from_numpy(np.stack(odd)).to(dev)
+    f, offs = ctx.sift_extract_batch_dev(stack.data_ptr(), 7, 243 * 325, 243, 325, 325, im.SiftParams(clahe=False))
+    kp, desc = f.download()
+    for b in range(7):
+        one = ctx.sift_extract(odd[b], im.SiftParams(clahe=False))
+        kp1, desc1 = one.download()
+        assert np.array_equal(kp[offs[b]:offs[b + 1]], kp1) and np.array_equal(desc[offs[b]:offs[b + 1]], desc1), b
+        one.free()
+    f.free()
+
+
 def test_match_chain_batch_equals_single(ctx, scene):
     m, frames = scene
     dev = torch.device("cuda", 0)
