@@ -1,0 +1,39 @@
+"""bench.py's output contract on a small workload (2048 x 2048 map, 8-frame steps), run in-process on the GPU: one JSON
+line with the driver's keys, the `roofline` and `cpu_baseline` objects, and a `parity` block that is green."""
+import json
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line(capsys, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--map-side", "2048", "--batch", "8",
+                                      "--frames", "16"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    bench.main()
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["unit"] == "frames/s"
+    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["data"] == "synthetic" and "workload" in out["config"] and "model" not in out["config"]
+    assert abs(out["value"] - 8 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+    p = out["parity"]
+    assert "error" not in p, p
+    assert p["keypoints_within_0.5px"] >= 0.99 and p["knn_idx_and_dist_bit_exact"] and p["ratio_decisions_identical"]
+    assert p["homography_corner_px_vs_oracle_max"] is None or p["homography_corner_px_vs_oracle_max"] <= 1.0
