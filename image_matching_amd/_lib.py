@@ -75,6 +75,8 @@ SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_int, c_u8p]),
     "imatch_draw_matches": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_u8p, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int, c_u8p]),
+    "imatch_draw_overlay": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
+                                           ctypes.c_int, c_u8p]),
     "imatch_knn2_f32": (ctypes.c_int, [c_vp, c_f32p, c_i64, c_f32p, c_i64, ctypes.c_int, c_i32p, c_f32p]),
     "imatch_fset_from_host": (ctypes.c_int, [c_vp, c_f32p, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_fset_count": (c_i64, [c_vp]),
@@ -193,9 +195,12 @@ class Features:
         return out
 
     def free(self):
-        if self._h is not None and self.ctx._h is not None:
-            self.ctx.lib.imatch_features_free(self._h)
-        self._h = None
+        # the pool the blocks go back to is the context's: same lock as every other call (re-entrant, so a finaliser
+        # running on the thread that holds it does not deadlock)
+        with self.ctx.lock:
+            if self._h is not None and self.ctx._h is not None:
+                self.ctx.lib.imatch_features_free(self._h)
+            self._h = None
 
     def __del__(self):
         try:
@@ -214,9 +219,10 @@ class FSet:
         return self.n
 
     def free(self):
-        if self._h is not None and self.ctx._h is not None:
-            self.ctx.lib.imatch_fset_free(self._h)
-        self._h = None
+        with self.ctx.lock:
+            if self._h is not None and self.ctx._h is not None:
+                self.ctx.lib.imatch_fset_free(self._h)
+            self._h = None
 
     def __del__(self):
         try:
@@ -240,7 +246,7 @@ class Context:
             raise ImatchError("imatch_init(device=%d) failed with code %d" % (device, rc))
         self._h = h
         self.device = int(device)
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()
 
     def _check(self, rc):
         if rc != 0:
@@ -391,6 +397,38 @@ class Context:
                                                      img1.strides[0], _ptr(img2, c_u8p), img2.shape[0], img2.shape[1],
                                                      img2.strides[0], _ptr(xy1, c_f32p), _ptr(xy2, c_f32p), len(xy1),
                                                      _ptr(out, c_u8p)))
+        return out
+
+    def draw_overlay(self, img, prims):
+        """Draw primitives on a copy of img (uint8 [h,w] or [h,w,3]) in order, on the GPU (imatch_draw_overlay).
+        prims: iterable of ("line", (x0, y0), (x1, y1), color, thickness) / ("circle", (x, y), radius, color, thickness)
+        with integer coordinates; color is a scalar or a per-channel tuple as cv2 takes it."""
+        img = np.asarray(img)
+        if img.ndim == 2:
+            img = self._gray(img)
+            ch = 1
+        else:
+            img = self._color(img)
+            ch = 3
+        rec = np.zeros((len(prims), 8), np.int32)
+        col = rec.view(np.uint8).reshape(len(prims), 32)
+        for i, p in enumerate(prims):
+            c = p[3]
+            c = (list(c) + [0, 0, 0, 0])[:4] if np.ndim(c) else [c, 0, 0, 0]     # cv2: a scalar colour is Scalar(v, 0, 0, 0)
+            lim = 1 << 20     # far-off coordinates (a wild homography) are clipped as cv2 clips them, not refused
+            x0, y0 = (int(min(max(v, -lim), lim)) for v in p[1])
+            if p[0] == "line":
+                x1, y1 = (int(min(max(v, -lim), lim)) for v in p[2])
+                rec[i, :6] = (0, x0, y0, x1, y1, p[4])
+            elif p[0] == "circle":
+                rec[i, :6] = (1, x0, y0, p[2], 0, p[4])
+            else:
+                raise ValueError("unknown primitive %r" % (p[0],))
+            col[i, 24:28] = np.clip(c, 0, 255)
+        out = np.empty(img.shape, np.uint8)
+        with self.lock:
+            self._check(self.lib.imatch_draw_overlay(self._h, _ptr(img, c_u8p), img.shape[0], img.shape[1], ch, img.strides[0],
+                                                     rec.ctypes.data_as(c_vp), len(prims), _ptr(out, c_u8p)))
         return out
 
     # -- AKAZE ------------------------------------------------------------------------------

@@ -16,6 +16,11 @@ struct imatch_ctx {
     // pinned host staging
     void* hs;
     size_t hs_bytes;
+    // an asynchronous host-to-device copy may still be reading hs after the call that queued it has returned (the sorted
+    // keypoint records of imatch_sift_extract): it records hs_ev, and imatch_hs_reserve -- which every writer of hs calls
+    // first -- waits for it
+    hipEvent_t hs_ev;
+    int hs_pending;
     // pinned staging of host images on their way to / from the device (see imatch_stage_upload)
     void* is;
     size_t is_bytes;
@@ -77,6 +82,8 @@ void* imatch_pool_alloc(imatch_ctx* ctx, size_t bytes);
 void imatch_pool_free(imatch_ctx* ctx, void* p);
 void imatch_pool_destroy(imatch_ctx* ctx);
 int imatch_hs_reserve(imatch_ctx* ctx, size_t bytes);
+// call after queueing a copy that reads ctx->hs and is not followed by a synchronisation before the call returns
+int imatch_hs_mark_busy(imatch_ctx* ctx);
 // Host worker pool (core.hip): runs fn(i) for i in [0, n) on up to 16 persistent threads of the context and returns
 // when all are done. The per-image sorts of a batch and the per-frame homography refits use it: spawning 16
 // std::threads per call cost about as much as the work itself.

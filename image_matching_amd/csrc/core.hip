@@ -144,7 +144,18 @@ void imatch_workers_destroy(imatch_ctx* ctx) {
     ctx->workers = nullptr;
 }
 
+int imatch_hs_mark_busy(imatch_ctx* ctx) {
+    if (!ctx->hs_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->hs_ev, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->hs_ev, ctx->stream));
+    ctx->hs_pending = 1;
+    return IMATCH_OK;
+}
+
 int imatch_hs_reserve(imatch_ctx* ctx, size_t bytes) {
+    if (ctx->hs_pending) {   // a queued copy still reads the block: the caller is about to write into it
+        HIP_TRY(ctx, hipEventSynchronize(ctx->hs_ev));
+        ctx->hs_pending = 0;
+    }
     if (bytes <= ctx->hs_bytes) return IMATCH_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->hs) HIP_TRY(ctx, hipHostFree(ctx->hs));
@@ -268,6 +279,7 @@ void imatch_destroy(imatch_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
     if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
+    if (ctx->hs_ev) (void)hipEventDestroy(ctx->hs_ev);
     (void)hipStreamDestroy(ctx->stream);
     free(ctx);
 }

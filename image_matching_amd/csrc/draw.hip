@@ -68,6 +68,100 @@ canvas_kernel(const uint8_t* __restrict__ img1, int h1, int w1, const uint8_t* _
     out[3 * p] = c0; out[3 * p + 1] = c1; out[3 * p + 2] = c2;
 }
 
+// ---- overlay primitives: the pose overlay of find_keypoints_transform (reference match_finder.py:249-250:
+// cv2.circle(img, c, 10, 255, 5) + cv2.polylines(img, [quad], True, 255, 3)) and the map marker of
+// utils.draw_circle_on_map_by_coord_and_angles (reference utils.py:75-76: cv2.line(.., color, 2) + cv2.circle(.., 4, color, 2)).
+// Same scheme as the match canvas: one wave per primitive rasterises into the owner plane (atomicMax on the primitive's
+// index: drawing in order), one pass composes. Pixels follow "Spec D" (oracle/draw_oracle.c): a thick line is the DDA line
+// stamped with a disc brush 4 (u^2 + v^2) <= t^2; a ring is (2r - t)^2 <= 4 d^2 < (2r + t)^2; thickness < 0 fills the disc.
+__global__ void __launch_bounds__(256)
+overlay_owner_kernel(const imatch_draw_prim* __restrict__ prims, int n, int H, int W, int* __restrict__ owner) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const imatch_draw_prim p = prims[i];
+    const int t = p.thickness;
+    if (p.kind == IMATCH_DRAW_LINE) {
+        const int dx = p.x1 - p.x0, dy = p.y1 - p.y0;
+        const int m = max(abs(dx), abs(dy));
+        const int hb = t / 2, S = 2 * hb + 1, SS = S * S;
+        const long long total = (long long)(m + 1) * SS;
+        for (long long e = lane; e < total; e += 64) {
+            const int k = (int)(e / SS), c = (int)(e % SS), u = c % S - hb, v = c / S - hb;
+            if (4 * (u * u + v * v) <= t * t)
+                put(owner, H, W, p.x0 + (m ? dda(k, dx, m) : 0) + u, p.y0 + (m ? dda(k, dy, m) : 0) + v, i);
+        }
+    } else {
+        const int r = p.x1;
+        const int R = r + (t > 0 ? (t + 1) / 2 : 0) + 1, S = 2 * R + 1;
+        const long long lo = (t > 0 && 2 * r > t) ? (long long)(2 * r - t) * (2 * r - t) : 0;
+        const long long hi = t > 0 ? (long long)(2 * r + t) * (2 * r + t) : 4LL * r * r + 1;
+        for (int e = lane; e < S * S; e += 64) {
+            const int u = e % S - R, v = e / S - R;
+            const long long d4 = 4LL * (u * u + v * v);
+            if (d4 >= lo && d4 < hi) put(owner, H, W, p.x0 + u, p.y0 + v, i);
+        }
+    }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256)
+overlay_compose_kernel(const uint8_t* __restrict__ img, const imatch_draw_prim* __restrict__ prims, const int* __restrict__ owner,
+                       int H, int W, uint8_t* __restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const size_t p = (size_t)y * W + x;
+    const int i = owner[p];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) out[CH * p + c] = i >= 0 ? prims[i].color[c] : img[CH * p + c];
+}
+
+extern "C" int imatch_draw_overlay(imatch_ctx* ctx, const uint8_t* img, int h, int w, int channels, int stride,
+                                   const imatch_draw_prim* prims, int n, uint8_t* out) {
+    if (!ctx || !img || !out || h <= 0 || w <= 0 || (channels != 1 && channels != 3) || stride < w * channels || n < 0 ||
+        (n > 0 && !prims))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    for (int i = 0; i < n; ++i) {
+        const imatch_draw_prim& p = prims[i];
+        const int lim = 1 << 20;
+        bool ok = (p.kind == IMATCH_DRAW_LINE || p.kind == IMATCH_DRAW_CIRCLE) && abs(p.x0) <= lim && abs(p.y0) <= lim &&
+                  p.thickness <= 255;
+        if (ok && p.kind == IMATCH_DRAW_LINE) ok = abs(p.x1) <= lim && abs(p.y1) <= lim && p.thickness >= 1;
+        if (ok && p.kind == IMATCH_DRAW_CIRCLE) ok = p.x1 >= 0 && p.x1 <= 4096 && p.thickness != 0;
+        if (!ok) return imatch_set_err(ctx, IMATCH_EINVAL, "primitive %d: kind, coordinates (|v| <= 2^20), radius (<= 4096) or "
+                                       "thickness (1..255; circles also < 0 = filled) out of range", i);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t row = (size_t)w * channels;
+    const size_t bi = up((size_t)h * row), bo = up((size_t)h * w * 4), bp = up((size_t)(n > 0 ? n : 1) * sizeof(imatch_draw_prim));
+    int rc = imatch_ws_reserve(ctx, 2 * bi + bo + bp);
+    if (rc) return rc;
+    uint8_t* d_img = (uint8_t*)ctx->ws;
+    int* owner = (int*)(d_img + bi);
+    uint8_t* d_out = (uint8_t*)owner + bo;
+    imatch_draw_prim* d_pr = (imatch_draw_prim*)(d_out + bi);
+    rc = imatch_hs_reserve(ctx, bi + bp);
+    if (rc) return rc;
+    uint8_t* hs = (uint8_t*)ctx->hs;
+    for (int y = 0; y < h; ++y) memcpy(hs + (size_t)y * row, img + (size_t)y * stride, row);
+    if (n > 0) memcpy(hs + bi, prims, (size_t)n * sizeof(imatch_draw_prim));
+    HIP_TRY(ctx, hipMemcpyAsync(d_img, hs, bi, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_pr, hs + bi, bp, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(owner, 0xff, (size_t)h * w * 4, ctx->stream));
+    if (n > 0) hipLaunchKernelGGL(overlay_owner_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, d_pr, n, h, w, owner);
+    if (channels == 1)
+        hipLaunchKernelGGL(overlay_compose_kernel<1>, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, d_img, d_pr, owner, h, w, d_out);
+    else
+        hipLaunchKernelGGL(overlay_compose_kernel<3>, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, d_img, d_pr, owner, h, w, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    rc = imatch_stage_download_begin(ctx, d_out, (size_t)h * row);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    imatch_stage_download_end(ctx, out, (size_t)h * row);
+    return IMATCH_OK;
+}
+
 extern "C" int imatch_draw_matches(imatch_ctx* ctx, const uint8_t* img1, int h1, int w1, int stride1, const uint8_t* img2,
                                    int h2, int w2, int stride2, const float* xy1, const float* xy2, int n, uint8_t* out) {
     if (!ctx || !img1 || !img2 || !out || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || stride1 < w1 || stride2 < w2 || n < 0 ||

@@ -737,6 +737,11 @@ static void launch_knn(imatch_ctx* ctx, const imatch_features* q, const imatch_f
 static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t idx_offset,
                     int32_t* out4_dev) {
     if (!ctx || !q || !t || !out4_dev) return imatch_set_err(ctx, IMATCH_EINVAL, "null argument");
+    // the bf16 rows and the integer casts of the merge are exact only for integers 0..255 (SIFT's descriptors); any other
+    // set would get wrong neighbours with rc 0
+    if (!q->integral || !t->integral)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "%s descriptor set is not integer valued in 0..255: the bf16 MFMA kernel is "
+                              "exact only for such sets; use imatch_knn2_f32", !q->integral ? "query" : "train");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (q->n == 0) return IMATCH_OK;
     // query tile per workgroup: 4 waves x 32*QB queries

@@ -1509,9 +1509,12 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             continue;
         }
         if (Ktot > 0) {
-            // the pinned rows are not rewritten before the next synchronisation on this context
+            // this copy is still reading the pinned rows when the call returns: the next writer of ctx->hs waits for it
+            // (imatch_hs_reserve)
             HIP_TRY(ctx, hipMemcpy2DAsync(d_sorted, zs, h_kp, (size_t)kp_hint * sizeof(KpRec), (size_t)max_k * sizeof(KpRec),
                                           (size_t)batch, hipMemcpyHostToDevice, ctx->stream));
+            rc = imatch_hs_mark_busy(ctx);
+            if (rc) { imatch_features_free(f); return rc; }
             if (max_k <= 65536)
                 hipLaunchKernelGGL(describe_kernel<4>, dim3(max_k, 1, batch), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted,
                                    seg, first_octave, d_desc, zs);

@@ -182,7 +182,12 @@ class match_finder():
                     train_dp.fset = self.ctx.fset(train_dp)
                 return self.ctx.knn2_f32(query_dp, train_dp.fset)
             return self.ctx.knn2_f32(query_dp, train_dp)
-        return self.ctx.knn2(_features_of(self.ctx, query_dp), _features_of(self.ctx, train_dp))
+        fq, ft = _features_of(self.ctx, query_dp), _features_of(self.ctx, train_dp)
+        if fq.integral and ft.integral:
+            return self.ctx.knn2(fq, ft)      # SIFT's integer rows: bf16 MFMA, exact
+        # 128 floats per row that are not integers 0..255 (RootSIFT, normalised rows, SURF-128): the MFMA kernel would
+        # round them; BFMatcher's f32 arithmetic is the float kernel's (match_finder.py:182-183)
+        return self.ctx.knn2_f32(np.asarray(query_dp, dtype=np.float32), np.asarray(train_dp, dtype=np.float32))
 
     def find_matches(self, roi, cadr):  # roi, cadr
         idx, dist = self.knn_match(cadr.dp, roi.dp)
@@ -228,8 +233,12 @@ class match_finder():
         if img_for_pub is not None:
             dst[:, 0, 0] += img1.shape[1]
             xc, yc = line_intersection((dst[0][0], dst[2][0]), (dst[1][0], dst[3][0]))
-            img_for_pub = draw.draw_circle(img_for_pub, (int(xc), int(yc)), 10, 255, 5)
-            img_for_pub = draw.draw_polyline(img_for_pub, np.int32(dst), 255, 3)
+            # cv2.circle(img, c, 10, 255, 5) + cv2.polylines(img, [np.int32(dst)], True, 255, 3) (match_finder.py:249-250;
+            # the scalar colour 255 is Scalar(255, 0, 0)): drawn on the GPU
+            q = np.int32(dst).reshape(4, 2)
+            prims = [("circle", (int(xc), int(yc)), 10, 255, 5)]
+            prims += [("line", tuple(int(v) for v in q[k]), tuple(int(v) for v in q[(k + 1) % 4]), 255, 3) for k in range(4)]
+            img_for_pub = self.ctx.draw_overlay(img_for_pub, prims)
         if isConv is True:
             roll, pitch, yaw = self.get_angles_from_homography(M)
             return x_center, y_center, roll, pitch, yaw, M, img_for_pub, answer

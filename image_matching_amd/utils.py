@@ -1,11 +1,16 @@
 """Host helpers of the hot path with the reference's behaviour (reference utils.py): resize_img
 (utils.py:17-22, the INTER_AREA resize now runs on the GPU), line_intersection (utils.py:46-60),
 CrossProduct (utils.py:79-84), isConvex (utils.py:86-143, messages included: the callers log them,
-position_finder.py:396-397,639), angle (utils.py:145-152), calculate_euqlidian_dist (utils.py:154-156)."""
+position_finder.py:396-397,639), angle (utils.py:145-152), calculate_euqlidian_dist (utils.py:154-156), and the three
+names the reference's nodes import besides them: check_exist (utils.py:8-14), rotate_image (utils.py:25-44),
+draw_circle_on_map_by_coord_and_angles (utils.py:62-77, drawn on the GPU)."""
 from decimal import Decimal
 from math import atan2, pi
+from os.path import exists
 
 import numpy as np
+
+from .geodetic_conv import GeodeticConvert
 
 _ctx = None
 
@@ -29,6 +34,70 @@ def resize_img(img, scale):
     width = int(img.shape[1] * Decimal(scale))
     height = int(img.shape[0] * Decimal(scale))
     return default_context().resize_area(img, (width, height))
+
+
+def check_exist(path, i=1):
+    """The loggers' unused-file-name probe (utils.py:8-14; image_logger.py:41,50,189, command_logger.py:21). As in the
+    reference the recursive call's result is dropped: a path that exists gives None, a free path comes back unchanged."""
+    print(path)
+    if exists(path) is True:
+        path = str(i) + '_' + path
+        check_exist(path, i=i + 1)
+    else:
+        return path
+
+
+def rotate_image(mat, angle):
+    """utils.py:25-44: rotate about the centre by `angle` degrees (counter-clockwise) into the bounding box of the
+    rotated image -- cv2.getRotationMatrix2D + cv2.warpAffine (bilinear, constant zero border). Imported by the
+    reference's match_finder.py:13 and never called; host numpy (float bilinear weights, not OpenCV's 5-bit fixed-point
+    ones: parity unpinned, as for everything OpenCV)."""
+    mat = np.asarray(mat)
+    height, width = mat.shape[:2]
+    cx, cy = width / 2, height / 2
+    a = np.deg2rad(angle)
+    alpha, beta = np.cos(a), np.sin(a)
+    M = np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]], np.float64)
+    abs_cos, abs_sin = abs(M[0, 0]), abs(M[0, 1])
+    bound_w = int(height * abs_sin + width * abs_cos)
+    bound_h = int(height * abs_cos + width * abs_sin)
+    M[0, 2] += bound_w / 2 - cx
+    M[1, 2] += bound_h / 2 - cy
+    # warpAffine maps destination pixels through the inverse transform
+    A = np.linalg.inv(np.vstack([M, [0, 0, 1]]))
+    xs, ys = np.meshgrid(np.arange(bound_w, dtype=np.float64), np.arange(bound_h, dtype=np.float64))
+    sx = A[0, 0] * xs + A[0, 1] * ys + A[0, 2]
+    sy = A[1, 0] * xs + A[1, 1] * ys + A[1, 2]
+    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+    fx, fy = sx - x0, sy - y0
+    src = mat.astype(np.float64).reshape(height, width, -1)
+    out = np.zeros((bound_h, bound_w, src.shape[2]), np.float64)
+    for dy, wy in ((0, 1 - fy), (1, fy)):
+        for dx, wx in ((0, 1 - fx), (1, fx)):
+            xx, yy = x0 + dx, y0 + dy
+            ok = (xx >= 0) & (xx < width) & (yy >= 0) & (yy < height)
+            v = src[np.clip(yy, 0, height - 1), np.clip(xx, 0, width - 1)]
+            out += np.where(ok, wx * wy, 0.0)[..., None] * v
+    out = np.clip(np.rint(out), 0, 255).astype(mat.dtype) if mat.dtype == np.uint8 else out.astype(mat.dtype)
+    return out.reshape((bound_h, bound_w) + mat.shape[2:])
+
+
+def draw_circle_on_map_by_coord_and_angles(img, coord, circle_coord, pixel_size, yaw, color):
+    """utils.py:62-77 (callers position_finder.py:333-346,382-388): mark the geodetic point circle_coord on the map
+    image whose top-left corner is at coord -- a circle of radius 4 and a 20-pixel heading line in `color`, both of
+    thickness 2 -- on a 3-channel copy of img. Drawn by imatch_draw_overlay on the GPU ("Spec D" pixels)."""
+    img = np.asarray(img)
+    if img.ndim == 2:                       # cv2.cvtColor(img, COLOR_GRAY2BGR); a colour image is kept as it is
+        img = np.repeat(img[:, :, None], 3, axis=2)
+    g_c = GeodeticConvert()
+    g_c.initialiseReference(coord[0], coord[1], 0)
+    y, x, z = g_c.geodetic2Ned(circle_coord[0], circle_coord[1], 0)
+    pixel_x = int(x / float(pixel_size))
+    pixel_y = int(-y / float(pixel_size))
+    x2 = int(pixel_x + 20 * np.sin(yaw))
+    y2 = int(pixel_y - 20 * np.cos(yaw))
+    return default_context().draw_overlay(img, [("line", (pixel_x, pixel_y), (x2, y2), color, 2),
+                                                ("circle", (pixel_x, pixel_y), 4, color, 2)])
 
 
 def line_intersection(line1, line2):

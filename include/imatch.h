@@ -107,6 +107,25 @@ int imatch_fisheye_undistort(imatch_ctx* ctx, const uint8_t* img, int h, int w, 
 int imatch_draw_matches(imatch_ctx* ctx, const uint8_t* img1, int h1, int w1, int stride1, const uint8_t* img2, int h2,
                         int w2, int stride2, const float* xy1, const float* xy2, int n, uint8_t* out);
 
+/* Replaces the drawing calls that mark a result on an image: the pose overlay of find_keypoints_transform,
+ * cv2.circle(img_for_pub, centre, 10, 255, 5) + cv2.polylines(img_for_pub, [np.int32(dst)], True, 255, 3, LINE_AA)
+ * (MF:249-250), and the map marker of utils.draw_circle_on_map_by_coord_and_angles, cv2.line(img, p, p2, color, 2) +
+ * cv2.circle(img, p, 4, color, 2) (utils.py:75-76; callers position_finder.py:333-346,382-388). img is 8-bit with 1 or 3
+ * interleaved channels, `stride` bytes per row; out is [h][w][channels]; the n primitives are drawn in order (a later one
+ * covers an earlier one), on the GPU. Integer coordinates, as the reference passes them. Pixels follow "Spec D"
+ * (oracle/draw_oracle.c): a line of thickness t is the integer DDA line stamped with the disc 4 (u^2 + v^2) <= t^2, a
+ * circle of radius r is the ring (2r - t)^2 <= 4 d^2 < (2r + t)^2 (thickness < 0: the filled disc); no anti-aliasing. */
+#define IMATCH_DRAW_LINE   0   /* (x0, y0) -> (x1, y1) */
+#define IMATCH_DRAW_CIRCLE 1   /* centre (x0, y0), radius x1 (y1 unused) */
+typedef struct imatch_draw_prim {
+    int32_t kind, x0, y0, x1, y1;
+    int32_t thickness;         /* 1..255; circles: < 0 = filled */
+    uint8_t color[4];          /* channel values in the image's own channel order (cv2's Scalar); 1-channel: color[0] */
+    int32_t reserved;
+} imatch_draw_prim;
+int imatch_draw_overlay(imatch_ctx* ctx, const uint8_t* img, int h, int w, int channels, int stride,
+                        const imatch_draw_prim* prims, int n, uint8_t* out);
+
 /* SIFT extraction ---------------------------------------------------------- */
 typedef struct imatch_sift_params {
     int n_octave_layers;       /* nOctaveLayers_sift   (MF:31), OpenCV default 3 */

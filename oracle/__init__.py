@@ -306,6 +306,8 @@ def _declare_draw(L):
     c_int = ctypes.c_int
     L.oracle_draw_matches.argtypes = [_u8p, c_int, c_int, _u8p, c_int, c_int, _f32p, _f32p, c_int, _u8p]
     L.oracle_draw_matches.restype = None
+    L.oracle_draw_overlay.argtypes = [_u8p, c_int, c_int, c_int, _i32p, c_int, _u8p]
+    L.oracle_draw_overlay.restype = None
 
 
 _declare_before_draw = _declare
@@ -325,6 +327,29 @@ def draw_matches(img1, xy1, img2, xy2):
     out = np.empty((max(img1.shape[0], img2.shape[0]), img1.shape[1] + img2.shape[1], 3), np.uint8)
     lib().oracle_draw_matches(_p(img1, _u8p), img1.shape[0], img1.shape[1], _p(img2, _u8p), img2.shape[0], img2.shape[1],
                               _p(xy1, _f32p), _p(xy2, _f32p), len(xy1), _p(out, _u8p))
+    return out
+
+
+def overlay_records(prims):
+    """("line", p0, p1, color, thickness) / ("circle", centre, radius, color, thickness) -> int32 [n][8] records."""
+    rec = np.zeros((len(prims), 8), np.int32)
+    col = rec.view(np.uint8).reshape(len(prims), 32)
+    for i, p in enumerate(prims):
+        c = p[3]
+        c = (list(c) + [0, 0, 0, 0])[:4] if np.ndim(c) else [c, 0, 0, 0]
+        rec[i, :6] = (0, p[1][0], p[1][1], p[2][0], p[2][1], p[4]) if p[0] == "line" else (1, p[1][0], p[1][1], p[2], 0, p[4])
+        col[i, 24:28] = np.clip(c, 0, 255)
+    return rec
+
+
+def draw_overlay(img, prims):
+    """Primitives drawn in order on a copy of img (u8 [h,w] or [h,w,3]) under "Spec D" (draw_oracle.c); follows
+    match_finder.py:249-250 and utils.py:75-76."""
+    img = np.ascontiguousarray(img, np.uint8)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    rec = overlay_records(prims)
+    out = np.empty(img.shape, np.uint8)
+    lib().oracle_draw_overlay(_p(img, _u8p), img.shape[0], img.shape[1], ch, _p(rec, _i32p), len(rec), _p(out, _u8p))
     return out
 
 

@@ -14,6 +14,16 @@
  *   - circles: the pixels with (2r - 1)^2 <= 4 (dx^2 + dy^2) < (2r + 1)^2 around both end points, r = 3;
  *   - colour of match i: channel c = 64 + (mix32(i * 3 + c) % 192); where several matches cover a pixel the one
  *     with the highest index wins (cv2 draws them in order too).
+ *
+ * oracle_draw_overlay follows the reference's other drawing calls: the pose overlay of find_keypoints_transform,
+ * match_finder.py:249-250 (cv2.circle(img, c, 10, 255, 5); cv2.polylines(img, [quad], True, 255, 3, LINE_AA)) and the map
+ * marker of utils.py:75-76 (cv2.line(img, p, p2, color, 2); cv2.circle(img, p, 4, color, 2)). Integer coordinates as the
+ * reference passes them; primitives are drawn in order. "Spec D" for them:
+ *   - line of thickness t: the DDA line above, every pixel stamped with the disc brush 4 (u^2 + v^2) <= t^2,
+ *     |u|, |v| <= t / 2 (integer division);
+ *   - circle of radius r, thickness t > 0: the ring (2r - t)^2 <= 4 (u^2 + v^2) < (2r + t)^2 (no lower bound when
+ *     2r <= t); t < 0: the filled disc u^2 + v^2 <= r^2;
+ *   - colour: the primitive's channel values as given (cv2's Scalar), channel 0 for a 1-channel image.
  */
 #include <math.h>
 #include <stdint.h>
@@ -72,5 +82,41 @@ void oracle_draw_matches(const uint8_t* img1, int h1, int w1, const uint8_t* img
                 o[0] = o[1] = o[2] = g;
             }
         }
+    free(owner);
+}
+
+/* prims: int32 [n][8] = kind (0 line, 1 circle), x0, y0, x1 (circle: radius), y1, thickness, colour bytes (4), reserved */
+void oracle_draw_overlay(const uint8_t* img, int h, int w, int ch, const int32_t* prims, int n, uint8_t* out) {
+    int32_t* owner = (int32_t*)malloc((size_t)h * w * sizeof(int32_t));
+    memset(owner, 0xff, (size_t)h * w * sizeof(int32_t));
+    for (int i = 0; i < n; ++i) {
+        const int32_t* p = prims + 8 * i;
+        const int x0 = p[1], y0 = p[2], t = p[5];
+        if (p[0] == 0) {
+            const int dx = p[3] - x0, dy = p[4] - y0;
+            const int m = abs(dx) > abs(dy) ? abs(dx) : abs(dy);
+            const int hb = t / 2;
+            for (int k = 0; k <= m; ++k) {
+                const int cx = x0 + (m ? dda(k, dx, m) : 0), cy = y0 + (m ? dda(k, dy, m) : 0);
+                for (int v = -hb; v <= hb; ++v)
+                    for (int u = -hb; u <= hb; ++u)
+                        if (4 * (u * u + v * v) <= t * t) put(owner, h, w, cx + u, cy + v, i);
+            }
+        } else {
+            const int r = p[3];
+            const int R = r + (t > 0 ? (t + 1) / 2 : 0) + 1;
+            const long long lo = (t > 0 && 2 * r > t) ? (long long)(2 * r - t) * (2 * r - t) : 0;
+            const long long hi = t > 0 ? (long long)(2 * r + t) * (2 * r + t) : 4LL * r * r + 1;
+            for (int v = -R; v <= R; ++v)
+                for (int u = -R; u <= R; ++u) {
+                    const long long d4 = 4LL * (u * u + v * v);
+                    if (d4 >= lo && d4 < hi) put(owner, h, w, x0 + u, y0 + v, i);
+                }
+        }
+    }
+    for (int64_t q = 0; q < (int64_t)h * w; ++q) {
+        const int i = owner[q];
+        for (int c = 0; c < ch; ++c) out[q * ch + c] = i >= 0 ? ((const uint8_t*)(prims + 8 * i + 6))[c] : img[q * ch + c];
+    }
     free(owner);
 }

@@ -50,3 +50,87 @@ def test_find_matches_returns_the_gpu_canvas(ctx):
     good, img3 = mf.find_matches(roi_t(img2, kp2, dp2, 1.0, 0, 0), cadr)
     want = oracle.draw_matches(img1, np.asarray(kp1.xy)[good.query_idx], img2, np.asarray(kp2.xy)[good.train_idx])
     assert img3.shape == (512, 160 + 512, 3) and np.array_equal(img3, want)
+
+
+# ---- overlay primitives: pose overlay (match_finder.py:249-250) and map marker (utils.py:62-77) -----------------
+def _prims(rng, n, w, h):
+    out = []
+    for i in range(n):
+        col = tuple(int(v) for v in rng.integers(0, 256, 3)) if i % 3 else int(rng.integers(0, 256))
+        if i % 2:
+            out.append(("circle", (int(rng.integers(-10, w + 10)), int(rng.integers(-10, h + 10))), int(rng.integers(0, 40)), col,
+                        int(rng.choice([1, 2, 3, 5, 9, -1]))))
+        else:
+            out.append(("line", (int(rng.integers(-30, w + 30)), int(rng.integers(-30, h + 30))),
+                        (int(rng.integers(-30, w + 30)), int(rng.integers(-30, h + 30))), col, int(rng.choice([1, 2, 3, 5, 8]))))
+    return out
+
+
+@pytest.mark.parametrize("shape", [(480, 1120, 3), (300, 301), (64, 64, 3), (1, 1), (9, 200, 3)])
+def test_overlay_bit_exact(ctx, shape):
+    rng = np.random.default_rng(sum(shape))
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    prims = _prims(rng, 40, shape[1], shape[0])
+    assert np.array_equal(ctx.draw_overlay(img, prims), oracle.draw_overlay(img, prims))
+    assert np.array_equal(ctx.draw_overlay(img, []), img)
+
+
+def test_overlay_rejects_what_it_cannot_draw(ctx):
+    import image_matching_amd as im
+    img = np.zeros((8, 8), np.uint8)
+    with pytest.raises(im.ImatchError):
+        ctx.draw_overlay(img, [("circle", (1, 1), 5000, 1, 1)])
+    with pytest.raises(im.ImatchError):
+        ctx.draw_overlay(img, [("line", (0, 0), (1, 1), 1, 0)])
+
+
+def test_pose_overlay_of_find_keypoints_transform(ctx):
+    """img_for_pub comes back with cv2.circle(.., 10, 255, 5) + cv2.polylines(.., 255, 3) drawn (match_finder.py:243-250)."""
+    from image_matching_amd import synth
+    from image_matching_amd.match_finder import line_intersection, match_finder, perspective_transform, roi as roi_t
+    from image_matching_amd.image_processing import image_processing
+    mf = match_finder(ctx)
+    m = synth.synth_map(768, seed=5)
+    frame, _ = synth.synth_frame(m, 1, size=(240, 320))
+    kp1, dp1, img1 = mf.find_kp_dp(frame)
+    kp2, dp2, img2 = mf.find_kp_dp(m)
+    cadr = image_processing(img=img1)
+    cadr.kp, cadr.dp = kp1, dp1
+    r = roi_t(img2, kp2, dp2, 1.0, 0, 0)
+    good, img3 = mf.find_matches(r, cadr)
+    assert len(good) > 10
+    res = mf.find_keypoints_transform(good, r, cadr, img3.copy())
+    M, pub = res[5], res[6]
+    assert M is not None and pub.shape == img3.shape
+    pts = np.float32([[0, 0], [0, 239], [319, 239], [319, 0]]).reshape(-1, 1, 2)
+    dst = perspective_transform(pts, M)
+    dst[:, 0, 0] += 320
+    xc, yc = line_intersection((dst[0][0], dst[2][0]), (dst[1][0], dst[3][0]))
+    q = np.int32(dst).reshape(4, 2)
+    prims = [("circle", (int(xc), int(yc)), 10, 255, 5)]
+    prims += [("line", tuple(map(int, q[k])), tuple(map(int, q[(k + 1) % 4])), 255, 3) for k in range(4)]
+    assert np.array_equal(pub, oracle.draw_overlay(img3, prims))
+    assert (pub != img3).any()
+
+
+def test_map_marker(ctx):
+    """utils.draw_circle_on_map_by_coord_and_angles (utils.py:62-77): gray input becomes 3-channel, marker at the geodetic
+    point's pixel, heading line of 20 pixels."""
+    from image_matching_amd import utils
+    from image_matching_amd.geodetic_conv import GeodeticConvert
+    utils.set_default_context(ctx)
+    m = np.random.default_rng(1).integers(0, 255, (300, 400), dtype=np.uint8)
+    origin = (55.75, 37.61)
+    g = GeodeticConvert()
+    g.initialiseReference(origin[0], origin[1], 0)
+    lat, lon, _ = g.ned2Geodetic(north=-100.0, east=150.0, down=0)
+    out = utils.draw_circle_on_map_by_coord_and_angles(m, origin, (lat, lon), 0.5 * 2, 0.5, (0, 0, 255))
+    y, x, _ = g.geodetic2Ned(lat, lon, 0)
+    px_, py_ = int(x / 1.0), int(-y / 1.0)
+    want = oracle.draw_overlay(np.repeat(m[:, :, None], 3, 2),
+                               [("line", (px_, py_), (int(px_ + 20 * np.sin(0.5)), int(py_ - 20 * np.cos(0.5))), (0, 0, 255), 2),
+                                ("circle", (px_, py_), 4, (0, 0, 255), 2)])
+    assert out.shape == (300, 400, 3) and np.array_equal(out, want)
+    assert tuple(out[py_ - 4, px_]) == (0, 0, 255) and abs(px_ - 150) <= 1 and abs(py_ - 100) <= 1
+    col = np.zeros((50, 60, 3), np.uint8)
+    assert utils.draw_circle_on_map_by_coord_and_angles(col, origin, origin, 1.0, 0.0, (1, 2, 3)).shape == (50, 60, 3)

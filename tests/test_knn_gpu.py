@@ -153,3 +153,35 @@ def test_large_map_properties(ctx):
         idx, dist = ctx.knn2(fq_w, ft_w)
         ridx, rdist = oracle.knn2(q_dev[sel].cpu().numpy(), t_dev[:w].cpu().numpy(), threads=8)
         assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+
+
+def test_fractional_rows_are_refused_by_the_mfma_entry_point_and_rerouted_by_the_facade(ctx):
+    """128 floats per row that are not integers 0..255 (RootSIFT, normalised rows): imatch_knn2 must not answer with
+    bf16-rounded neighbours and rc 0 -- the C call errors, the facade sends the matrices through the float kernel and
+    gives BFMatcher's f32 answer (match_finder.py:182-183)."""
+    import image_matching_amd as im
+    from image_matching_amd.match_finder import match_finder
+    rng = np.random.default_rng(12)
+    t = np.sqrt(synth.synth_descriptors(3000, seed=3).astype(np.float32) / 512.0)      # RootSIFT-like rows
+    q = (t[rng.integers(0, 3000, 200)] + rng.normal(0, 0.01, (200, 128))).astype(np.float32)
+    fq, ft = ctx.features(q), ctx.features(t)
+    assert not fq.integral and not ft.integral
+    with pytest.raises(im.ImatchError, match="not integer valued"):
+        ctx.knn2(fq, ft)
+    ints = ctx.features(synth.synth_descriptors(100, seed=4))
+    with pytest.raises(im.ImatchError, match="not integer valued"):
+        ctx.knn2(ints, ft)                                 # one fractional side is enough
+    with pytest.raises(im.ImatchError, match="not integer valued"):
+        import torch
+        out = torch.empty((100, 4), dtype=torch.int32, device="cuda:0")
+        ctx.knn2_dev(ints, ft, out.data_ptr())
+    mf = match_finder(ctx)
+    idx, dist = mf.knn_match(q, t)
+    ridx, rdist = oracle.knn2(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    # integer rows handed over as plain float matrices still take the MFMA path and its exact answer
+    ti = synth.synth_descriptors(3000, seed=3)
+    qi, _, _ = synth.synth_queries(ti, 200, seed=5, dup_frac=0.1)
+    idx, dist = mf.knn_match(qi.astype(np.float32), ti.astype(np.float32))
+    ridx, rdist = oracle.knn2(qi, ti)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)

@@ -149,3 +149,24 @@ def test_non_default_params(ctx, small_map):
     kp, desc = f.download()
     idx, dist = _match_keypoints(kp, want.kp)
     assert (idx >= 0).mean() >= 0.99
+
+
+def test_calls_right_after_an_extraction_do_not_disturb_its_descriptors(ctx):
+    """imatch_sift_extract returns with the upload of its sorted keypoint records still queued (they sit in the context's
+    pinned block); a call that fills the same block next -- homography, the float kNN, the canvas -- must wait for it."""
+    from image_matching_amd import synth
+    m = synth.synth_map(1024, seed=9)
+    ref_kp, ref_desc = ctx.sift_extract(m).download()
+    rng = np.random.default_rng(0)
+    src = (rng.random((3000, 2)) * 500).astype(np.float32)
+    for follow in ("homography", "knn_f32", "canvas"):
+        f = ctx.sift_extract(m)
+        if follow == "homography":
+            ctx.homography(src, src * 1.5 + 3, 0.1, seed=1)
+        elif follow == "knn_f32":
+            ctx.knn2_f32(rng.random((4000, 64), dtype=np.float32), rng.random((500, 64), dtype=np.float32))
+        else:
+            ctx.draw_matches(m[:300, :400], src[:500], m[:200, :300], src[:500])
+        kp, desc = f.download()
+        assert np.array_equal(kp, ref_kp) and np.array_equal(desc, ref_desc), follow
+        f.free()
