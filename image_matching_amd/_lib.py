@@ -114,6 +114,7 @@ SIGNATURES = {
                                          ctypes.POINTER(ctypes.c_double), c_u8p, ctypes.POINTER(ctypes.c_int)]),
     "imatch_knn2": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32p, c_f32p]),
     "imatch_knn2_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
+    "imatch_knn2_noalloc_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
     "imatch_merge_top2_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, c_vp]),
     "imatch_ratio_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_double, c_i32p, c_i32p, c_f32p,
                                         ctypes.POINTER(c_i64)]),
@@ -609,6 +610,11 @@ class Context:
     def knn2_dev(self, q, t, out4_ptr, idx_offset=0):
         with self.lock:
             self._check(self.lib.imatch_knn2_dev(self._h, q._h, t._h, int(idx_offset), c_vp(out4_ptr)))
+
+    def knn2_noalloc_dev(self, q, t, out4_ptr, idx_offset=0):
+        """knn2_dev with the scratch in the library's fixed per-GPU block: no allocation (imatch_knn2_noalloc_dev)."""
+        with self.lock:
+            self._check(self.lib.imatch_knn2_noalloc_dev(self._h, q._h, t._h, int(idx_offset), c_vp(out4_ptr)))
 
     def merge_top2_dev(self, in4_ptr, n_lists, nq, out4_ptr):
         with self.lock:

@@ -70,6 +70,8 @@ int imatch_features_pack_u8_dev(imatch_ctx* ctx, imatch_features* f, const uint8
 // rows of image b are read from src_dev + b*zs (bytes) + (row - off[b])*128
 int imatch_features_pack_u8_seg_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev, const imatch_segtab* seg,
                                     size_t zs);
+// looks up the device address of the kNN scratch array for ctx->device (knn.hip; called by imatch_init)
+int imatch_knn2_scratch_setup(imatch_ctx* ctx);
 void imatch_sift_state_free(imatch_ctx* ctx);
 void imatch_camera_state_free(imatch_ctx* ctx);
 void imatch_akaze_state_free(imatch_ctx* ctx);

@@ -259,6 +259,11 @@ int imatch_init(int device, imatch_ctx** out) {
         free(c);
         return IMATCH_EHIP;
     }
+    if (imatch_knn2_scratch_setup(c) != IMATCH_OK) {   // per-device address of the fixed kNN scratch block
+        (void)hipStreamDestroy(c->stream);
+        free(c);
+        return IMATCH_EHIP;
+    }
     *out = c;
     return IMATCH_OK;
 }

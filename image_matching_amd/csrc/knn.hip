@@ -18,6 +18,7 @@
 #include <float.h>
 #include <limits.h>
 #include <math.h>
+#include <mutex>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -734,8 +735,33 @@ static void launch_knn(imatch_ctx* ctx, const imatch_features* q, const imatch_f
                        (const uint4*)t->desc, t->hneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr);
 }
 
+// ---- scratch of the entry point that allocates nothing (imatch_knn2_noalloc_dev) -----------------------------------
+// The launcher's scratch -- one partial top-2 list per (train chunk, query) and three bound words per query -- normally
+// lives in the context's growable workspace (hipMalloc on growth). Callers that cannot allocate get it from this
+// file-scope device array instead: 64 MiB per GPU, held until the process ends. In host code the array's NAME is only a
+// stand-in, not a device address; the per-device address is looked up once per device, with that device current
+// (imatch_init calls imatch_knn2_scratch_setup), and kept here.
+#define KNN_SCRATCH_BYTES ((size_t)64 << 20)
+#define KNN_SCRATCH_MAX_DEV 64
+static __device__ __align__(256) unsigned char knn_scratch[KNN_SCRATCH_BYTES];
+static void* knn_scratch_ptr[KNN_SCRATCH_MAX_DEV];   // device addresses of knn_scratch, one per GPU
+static std::mutex knn_scratch_mu;
+
+int imatch_knn2_scratch_setup(imatch_ctx* ctx) {
+    if (ctx->device < 0 || ctx->device >= KNN_SCRATCH_MAX_DEV) return IMATCH_OK;   // the entry point reports it
+    std::lock_guard<std::mutex> lk(knn_scratch_mu);
+    if (knn_scratch_ptr[ctx->device]) return IMATCH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    HIP_TRY(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(knn_scratch)));
+    if (!p) return imatch_set_err(ctx, IMATCH_EHIP, "hipGetSymbolAddress gave no address for the kNN scratch array");
+    knn_scratch_ptr[ctx->device] = p;
+    return IMATCH_OK;
+}
+
+// ws == nullptr: the scratch comes from the context's workspace (grown on demand); else from the ws_cap bytes at ws.
 static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t idx_offset,
-                    int32_t* out4_dev) {
+                    int32_t* out4_dev, void* ws = nullptr, size_t ws_cap = 0) {
     if (!ctx || !q || !t || !out4_dev) return imatch_set_err(ctx, IMATCH_EINVAL, "null argument");
     // the bf16 rows and the integer casts of the merge are exact only for integers 0..255 (SIFT's descriptors); any other
     // set would get wrong neighbours with rc 0
@@ -779,14 +805,26 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     if (nChunks > nStages / 4) nChunks = (nStages / 4 / 8) * 8;
     if (nChunks < 8) nChunks = 8;
     if (const char* e = getenv("IMATCH_KNN_CHUNKS")) nChunks = std::max(8, atoi(e) / 8 * 8);  // tuning override
-    const int64_t nLists = (int64_t)nChunks * (use16 ? 1 : 2);   // the 16x16x32 kernel merges its four row quarters itself
-    const size_t pbytes = (size_t)nLists * Qpad * 8;
+    const int lists_per_chunk = use16 ? 1 : 2;   // the 16x16x32 kernel merges its four row quarters itself
     const size_t gbytes = ((size_t)Qpad * 12 + 255) & ~(size_t)255;   // three bounds per query
-    int rc = imatch_ws_reserve(ctx, 2 * pbytes + gbytes);
-    if (rc) return rc;
-    float2* pb = (float2*)ctx->ws;
-    int2* pi = (int2*)((char*)ctx->ws + pbytes);
-    int* gthr = (int*)((char*)ctx->ws + 2 * pbytes);
+    if (ws) {   // a fixed scratch block: fewer, longer chunks until the partial lists fit
+        const size_t per_chunk = (size_t)lists_per_chunk * Qpad * 16;
+        const size_t room = ws_cap > gbytes ? (ws_cap - gbytes) / per_chunk : 0;
+        if (room < 8)
+            return imatch_set_err(ctx, IMATCH_ESIZE, "%lld queries need %zu bytes of kNN scratch, the fixed block holds %zu "
+                                  "(at most 262144 queries per call)", (long long)q->n, 8 * per_chunk + gbytes, ws_cap);
+        nChunks = std::min(nChunks, (int)(room / 8) * 8);
+    }
+    const int64_t nLists = (int64_t)nChunks * lists_per_chunk;
+    const size_t pbytes = (size_t)nLists * Qpad * 8;
+    if (!ws) {
+        int rc = imatch_ws_reserve(ctx, 2 * pbytes + gbytes);
+        if (rc) return rc;
+        ws = ctx->ws;
+    }
+    float2* pb = (float2*)ws;
+    int2* pi = (int2*)((char*)ws + pbytes);
+    int* gthr = (int*)((char*)ws + 2 * pbytes);
     HIP_TRY(ctx, hipMemsetAsync(gthr, 0x7f, gbytes, ctx->stream));  // 0x7f7f7f7f = 3.39e38 as a float
     if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (use16) {
@@ -866,6 +904,19 @@ void imatch_features_free(imatch_features* f) {
 int imatch_knn2_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t idx_offset,
                     int32_t* out4_dev) {
     return knn2_run(ctx, q, t, idx_offset, out4_dev);
+}
+
+int imatch_knn2_noalloc_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t idx_offset,
+                            int32_t* out4_dev) {
+    if (!ctx || !q || !t || !out4_dev) return imatch_set_err(ctx, IMATCH_EINVAL, "null argument");
+    if (ctx->device < 0 || ctx->device >= KNN_SCRATCH_MAX_DEV || !knn_scratch_ptr[ctx->device])
+        return imatch_set_err(ctx, IMATCH_EINVAL, "no kNN scratch block on device %d (set up by imatch_init; devices 0..%d)",
+                              ctx->device, KNN_SCRATCH_MAX_DEV - 1);
+    if (q->n > 262144)
+        return imatch_set_err(ctx, IMATCH_ESIZE, "%lld queries: the entry point that allocates nothing takes at most 262144 per call",
+                              (long long)q->n);
+    // every kernel argument and the memset below take the looked-up device address, never the array's name
+    return knn2_run(ctx, q, t, idx_offset, out4_dev, knn_scratch_ptr[ctx->device], KNN_SCRATCH_BYTES);
 }
 
 int imatch_knn2(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t* idx, float* dist) {

@@ -211,6 +211,16 @@ int imatch_knn2(imatch_ctx* ctx, const imatch_features* q, const imatch_features
  * context's stream; a missing neighbour is (INT32_MAX, -1). */
 int imatch_knn2_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t,
                     int32_t idx_offset, int32_t* out4_dev);
+/* imatch_knn2_dev for callers that cannot allocate. No counterpart in the reference: it is for code that must not call
+ * hipMalloc / hipFree -- a region under HIP graph capture, a tight serving loop, a harness that forbids allocation.
+ * Same arguments and the same result, bit for bit, as imatch_knn2_dev; the launcher's scratch (per-chunk partial top-2
+ * lists and three bound words per query) comes from a fixed 64 MiB device array inside the library, one per GPU, held
+ * until the process ends, instead of the context's growable workspace. Limit: at most 262144 queries per call (any
+ * number of train rows; with many queries the map is walked in fewer, longer chunks so that the lists fit), beyond that
+ * IMATCH_ESIZE. The call makes no hipMalloc, hipFree or other allocating call. All calls on one GPU share that GPU's
+ * array: calls that overlap in time on one GPU (two contexts, two streams) race; serialise them. */
+int imatch_knn2_noalloc_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t,
+                            int32_t idx_offset, int32_t* out4_dev);
 /* The same query for float descriptors of any length d <= 128 (the 64-float M-SURF descriptors of the AKAZE path,
  * MF:182-183 with MF:210-211): dist = sqrtf of the f32 sum of squared differences accumulated in index order, ties
  * to the lower train index. Host pointers; q is [nq][d], t is [nt][d]. */
