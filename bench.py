@@ -13,19 +13,23 @@ matches, position_finder.py:316). Per frame the results are identical to the sin
 (tests/test_batch_gpu.py); --batch 1 runs those instead, and their latency is reported beside the
 headline as "single_frame".
 
-At N > 1 every rank takes its OWN batches (frames are independent units: data-parallel, per-GPU work per step
-constant, total frames per step = N * batch: "scaling": "weak"; value = N * batch * steps / wall time, wall =
-max over ranks between two barriers). What happens to the map depends on its size (--map-mode):
-  replicated  a map whose descriptor set fits one GPU many times over (configs[1]'s does: 60 MB) lives on every
-              rank whole; no data-path collective (auto picks this below 16 GiB of packed descriptors);
-  sharded     the map's descriptors are split over the ranks by contiguous index ranges, queries are
-              all-gathered, every rank matches all batches against its shard, and an all_to_all returns the
-              per-shard top-2 to the batch's owner (image_matching_amd/sharded.py: the layout of configs[3]/[4],
-              maps of 5M-20M descriptors).
-In replicated mode a short sharded loop is run AFTER the headline is final and reported beside it as "sharded_map":
-one batch compared bit for bit with the whole-map result, then 10 timed steps. It runs under a watchdog
-(IMATCH_BENCH_EXTRA_TIMEOUT seconds, default 120): a failure or a stuck collective there is reported in that
-field and cannot change or withhold `value`. IMATCH_BENCH_SHARDED_EXTRA=0 skips it.
+Workloads (--workload; "auto" = c1 at N = 1, c3 at N > 1):
+  c1  BASELINE configs[1]: the map's own descriptors (236 k rows for the 8192^2 orthomap), whole on every GPU. At N > 1
+      frames are data-parallel and there is no collective.
+  c3  BASELINE configs[3]: a 5 M-row map (--map-rows) = the orthomap's real descriptors followed by SURVEY 8(d)'s synthetic
+      ones, SHARDED over the ranks by contiguous index ranges (image_matching_amd/sharded.py, match_dp): every rank takes
+      its own batch, the batches' descriptor rows are all-gathered as bytes, every rank matches all of them against its
+      shard (one MFMA launch), an all_to_all returns the per-shard top-2 to the batch's owner, merge_top2 picks the
+      winners. Per-GPU work per step is constant in N: "scaling": "weak"; value = N * batch * steps / wall.
+  c5  BASELINE configs[4]: 32 frames per step against a 20 M-row map sharded the same way, the frames REPLICATED (every
+      rank extracts the same batch: north_star's pattern, match_replicated): per-shard top-2 -> all_gather -> merge.
+      Total work per step is fixed: "scaling": "strong"; value = batch * steps / wall.
+wall = max over ranks between two barriers. At N > 1 the line also carries the per-rank kNN roofline fractions, the
+exchange time per step, and the world size RCCL reports.
+
+Launch: under torchrun (WORLD_SIZE set) every process is one rank. Without it, `python bench.py --gpus N` with N > 1 starts
+the N ranks itself as child processes -- before anything in this process has touched torch or the GPU -- relays rank 0's
+line and exits with the first non-zero child status.
 
 One JSON line on stdout (rank 0). Progress goes to stderr."""
 import argparse
@@ -42,6 +46,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA (spec)
 PYRAMID_BYTES_PER_INPUT_PIXEL = 475.7
+# What the scale-space kernels actually move: per octave pixel 5 blurs x (4 B read + 4 B write) + the scan's
+# six layer reads (24 B) = 64 B, octave pixels sum to (4/3) * 4 per input pixel; the base blur reads 1 B per input pixel
+# and writes 4 B per doubled pixel (16 B per input pixel): 64 * 16 / 3 + 17 = 358.3 B per input pixel.
+PYRAMID_BYTES_MOVED_PER_INPUT_PIXEL = 64.0 * 16.0 / 3.0 + 17.0
 
 
 def log(*a):
@@ -185,25 +193,88 @@ def akaze_extra(ctx, map_img, ratio):
         return {"error": repr(e)[:300]}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["auto", "c1", "c3", "c5"], default="auto",
+                    help="c1: configs[1], the map's own descriptors whole on every GPU; c3: configs[3], a 5 M-row map sharded "
+                         "over the ranks, frames data-parallel; c5: configs[4], 32 replicated frames vs a 20 M-row sharded map; "
+                         "auto = c1 at N = 1, c3 at N > 1")
     ap.add_argument("--map-side", type=int, default=8192)
+    ap.add_argument("--map-rows", type=int, default=0, help="total descriptor rows of the c3 / c5 map (default 5 M / 20 M)")
     ap.add_argument("--frames", type=int, default=128, help="distinct synthetic frames per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=64,
+    ap.add_argument("--batch", type=int, default=0,
                     help="frames per step and GPU, taken through the batched entry points (one launch per stage for "
-                         "the whole batch, one kNN launch over all frames' keypoints); 1 = the single-frame calls")
-    ap.add_argument("--map-mode", choices=["auto", "replicated", "sharded"], default="auto",
-                    help="N > 1: whole map on every rank (no collective) or map rows sharded over the ranks (all_gather + "
-                         "all_to_all per step); auto = replicated when the packed descriptor set is below 16 GiB")
+                         "the whole batch, one kNN launch over all frames' keypoints); 1 = the single-frame calls; "
+                         "default 64 (c5: 32)")
     ap.add_argument("--streams", type=int, default=1,
                     help="frames in flight per GPU: each has its own context (stream + arena) and host thread; a step is "
                          "then one frame per stream")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process -- which has not
+    imported torch or touched the GPU, and never will -- relay rank 0's stdout, exit with the first non-zero status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while any(pr.poll() is None for pr in procs):
+        failed = [pr.returncode for pr in procs if pr.poll() not in (None, 0)]
+        if failed:   # a rank died: the others would sit in a collective until RCCL's own timeout -- end exactly these children
+            rc = failed[0]
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.terminate()
+            t_end = time.time() + 10
+            for pr in procs:
+                try:
+                    pr.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    pr.wait()
+            break
+        time.sleep(0.2)
+    for pr in procs:
+        rc = rc or (pr.returncode or 0)
+    reader.join(timeout=5)
+    if got:
+        sys.stdout.write(got[0].decode())
+        sys.stdout.flush()
+    return rc
+
+
+def filler_xy(idx, side):
+    """Map position of a synthetic (keypoint-less) descriptor row: a fixed pseudo-random pixel, so that a false match with
+    such a row is an outlier for the homography like any other."""
+    idx = np.asarray(idx, dtype=np.int64)
+    return np.stack([(idx * 2654435761 % 1000003) % side, (idx * 40503 % 999983) % side], axis=1).astype(np.float32)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+
+    if os.environ.get("IMATCH_BENCH_HANG_DUMP"):      # debugging aid: every thread's stack on stderr after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["IMATCH_BENCH_HANG_DUMP"]), exit=True)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,6 +295,9 @@ def main():
         log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    workload = args.workload if args.workload != "auto" else ("c1" if world == 1 else "c3")
+    replicated_frames = workload == "c5"
+    B = args.batch if args.batch > 0 else (32 if workload == "c5" else 64)
 
     import image_matching_amd as im
     from image_matching_amd import sharded, synth
@@ -232,7 +306,7 @@ def main():
     ratio = 0.7
     params = im.SiftParams()
 
-    # ---- the map: generated and extracted once; descriptors stay in HBM
+    # ---- the orthomap: generated and extracted once; its descriptors are the map (c1) or the map's real rows (c3, c5)
     t0 = time.time()
     map_img = synth.synth_map(args.map_side, seed=1234)
     log("[rank %d] synthetic map %dx%d in %.1fs" % (rank, args.map_side, args.map_side, time.time() - t0))
@@ -245,41 +319,58 @@ def main():
     t_map_extract2 = time.time() - t0
     pyr_ms_map = min(pyr_ms_map, ctx.sift_pyramid_ms())
     f_map2.free()
-    n_map = len(f_map)
+    n_real = len(f_map)
     map_kp = f_map.download(descriptors=False)[0]
     map_xy = np.ascontiguousarray(map_kp[:, :2])
     log("[rank %d] map: %d descriptors, extract %.2fs (first) %.2fs (warm), scale-space stage %.2f ms"
-        % (rank, n_map, t_map_extract, t_map_extract2, pyr_ms_map))
-    map_mode = args.map_mode
-    if map_mode == "auto":
-        map_mode = "replicated" if n_map * 264 < (16 << 30) else "sharded"
-    if world == 1:
-        map_mode = "replicated"
-    lo, hi = sharded.partition(n_map, world)[rank]
-    f_shard = None
-    if world > 1:
-        all_u8 = torch.empty((n_map, 128), dtype=torch.uint8, device=dev)
-        f_map.desc_u8_dev(all_u8.data_ptr())
-        ctx.synchronize()
-        shard_u8 = all_u8[lo:hi].contiguous()
-        f_shard = ctx.features_from_device_u8(shard_u8.data_ptr(), hi - lo)
-        del all_u8
-    if map_mode == "replicated":
-        matcher = sharded.ShardedMatcher(ctx, f_map, 0, dev, local_only=True)
-        n_local = n_map
-    else:
-        matcher = sharded.ShardedMatcher(ctx, f_shard, lo, dev)
-        n_local = hi - lo
-    f_local = f_map if map_mode == "replicated" else f_shard
+        % (rank, n_real, t_map_extract, t_map_extract2, pyr_ms_map))
 
-    # ---- frames: each rank has its own set, resident in HBM before the timed region
-    frames_t = [synth.synth_frame(map_img, 100 * rank + i, size=(480, 640)) for i in range(args.frames)]
+    # ---- the descriptor map of the workload, resident in HBM
+    if workload == "c1":
+        n_map, lo, hi = n_real, 0, n_real
+        f_local = f_map
+        matcher = sharded.ShardedMatcher(ctx, f_map, 0, dev, local_only=True)
+    else:
+        n_map = args.map_rows if args.map_rows > 0 else (5_000_000 if workload == "c3" else 20_000_000)
+        n_map = max(n_map, n_real)
+        lo, hi = sharded.partition(n_map, world)[rank]
+        t0 = time.time()
+        shard_u8 = torch.empty((hi - lo, 128), dtype=torch.uint8, device=dev)
+        if lo < n_real:      # rows [0, n_real) are the orthomap's own descriptors ...
+            real_u8 = torch.empty((n_real, 128), dtype=torch.uint8, device=dev)
+            f_map.desc_u8_dev(real_u8.data_ptr())
+            ctx.synchronize()
+            shard_u8[:min(hi, n_real) - lo] = real_u8[lo:min(hi, n_real)]
+            del real_u8
+        if hi > n_real:      # ... the rest SURVEY 8(d)'s synthetic ones (any row range is reproducible on its own)
+            a = max(lo, n_real)
+            shard_u8[a - lo:] = synth.synth_descriptors_dev(a - n_real, hi - n_real, dev, seed=7)
+        torch.cuda.synchronize(dev)
+        f_local = ctx.features_from_device_u8(shard_u8.data_ptr(), hi - lo)
+        del shard_u8
+        matcher = sharded.ShardedMatcher(ctx, f_local, lo, dev)
+        log("[rank %d] descriptor map: %d rows (%d real + synthetic), shard rows %d..%d resident in %.1fs"
+            % (rank, n_map, n_real, lo, hi, time.time() - t0))
+    n_local = hi - lo
+
+    def xy_of(gt):
+        gt = np.asarray(gt, dtype=np.int64)
+        if n_map == n_real:
+            return map_xy[gt]
+        out = filler_xy(gt, args.map_side)
+        real = gt < n_real
+        out[real] = map_xy[gt[real]]
+        return out
+
+    # ---- frames: each rank has its own set (c5: every rank the same), resident in HBM before the timed region
+    frame_seed0 = 0 if replicated_frames else 100 * rank
+    frames_t = [synth.synth_frame(map_img, frame_seed0 + i, size=(480, 640)) for i in range(args.frames)]
     frames_h = [f for f, _ in frames_t]
     truth_H = [h for _, h in frames_t]
     frames_d = [torch.from_numpy(f).to(dev) for f in frames_h]
     q_cap = 4096                     # rows per frame in the exchange / result buffers (frames here have ~3000 keypoints)
 
-    stats = {"kp": [], "good": [], "found": 0, "knn_ms": [], "pyr_ms": []}
+    stats = {"kp": [], "good": [], "found": 0, "knn_ms": [], "pyr_ms": [], "q_launch": []}
 
     # extra frames in flight: one context (stream, arena, workspace) and one matcher per stream
     n_streams = max(1, args.streams)
@@ -289,10 +380,14 @@ def main():
     ctxs = [ctx] + [im.Context(local_rank) for _ in range(n_streams - 1)]
     for c in ctxs[1:]:
         c.set_profiling(True)
-    matchers = [matcher] + [sharded.ShardedMatcher(c, f_local, 0 if map_mode == "replicated" else lo, dev,
-                                                    local_only=map_mode == "replicated") for c in ctxs[1:]]
+    matchers = [matcher] + [sharded.ShardedMatcher(c, f_local, lo, dev, local_only=workload == "c1") for c in ctxs[1:]]
     import threading
     stats_lock = threading.Lock()
+
+    def match(mt, f, nq, cap):
+        if replicated_frames:
+            return mt.match_replicated(f, nq)
+        return mt.match_dp(f, nq, cap)
 
     def step(i, record=False, lane=0):
         cx, mt = ctxs[lane], matchers[lane]
@@ -302,40 +397,42 @@ def main():
         pyr_ms = cx.sift_pyramid_ms() if record else 0.0
         if nq > q_cap:
             raise RuntimeError('frame has %d keypoints, exchange buffers hold %d' % (nq, q_cap))
-        out4 = mt.match_dp(f, nq, q_cap)
-        gq, gt, gd = cx.ratio_dev(out4.data_ptr(), out4.shape[0], ratio)
+        out4 = match(mt, f, nq, q_cap)
+        gq, gt, gd = cx.ratio_dev(out4.data_ptr(), nq, ratio)
         knn_ms = cx.knn2_kernel_ms() if record else 0.0
         H = None
         if len(gq) > 10:                                   # position_finder.py:316
             kp = f.download(descriptors=False)[0]
-            H, _ = cx.homography(kp[gq, :2], map_xy[gt], 0.1, seed=i)
+            H, _ = cx.homography(kp[gq, :2], xy_of(gt), 0.1, seed=i)
         f.free()
         if record:
             with stats_lock:
                 stats["pyr_ms"].append(pyr_ms)
                 stats["knn_ms"].append(knn_ms)
                 stats["kp"].append(nq)
+                stats["q_launch"].append(sum(mt.last_counts) if (mt.world > 1 and not replicated_frames) else nq)
                 stats["good"].append(len(gq))
                 stats["found"] += H is not None
         return H
 
     # batched steps: B frames resident as one [B,480,640] tensor per step
-    B = max(1, args.batch)
     bq_cap = ((B * 3200 + 1023) // 1024) * 1024      # rows per batch in the exchange / result buffers (frames: ~2940 each)
     if B > 1:
         n_sets = max(2, (len(frames_h) + B - 1) // B)
         batches_d = [torch.from_numpy(np.stack([frames_h[(j * B + k) % len(frames_h)] for k in range(B)])).to(dev)
                      for j in range(n_sets)]
 
-    def step_batch(i, record=False, lane=0, mt=None):
-        cx, mt = ctxs[lane], (mt if mt is not None else matchers[lane])
+    def step_batch(i, record=False, lane=0):
+        cx, mt = ctxs[lane], matchers[lane]
         fr = batches_d[(i * n_streams + lane) % len(batches_d)]
         f, offs = cx.sift_extract_batch_dev(fr.data_ptr(), B, 480 * 640, 480, 640, 640, params)
         nq = len(f)
         pyr_ms = cx.sift_pyramid_ms() if record else 0.0
         if nq > bq_cap:
             raise RuntimeError('batch has %d keypoints, buffers hold %d' % (nq, bq_cap))
-        out4 = mt.match_dp(f, nq, bq_cap)
+        if os.environ.get("IMATCH_BENCH_TRACE"):
+            log("[rank %d] step %d: %d query rows" % (rank, i, nq))
+        out4 = match(mt, f, nq, bq_cap)
         gq, gt, gd, goff = cx.ratio_batch_dev(out4.data_ptr(), offs, ratio)
         knn_ms = cx.knn2_kernel_ms() if record else 0.0
         ng = np.diff(goff)
@@ -347,13 +444,14 @@ def main():
             keep = np.repeat(use, ng)
             src, gt_u = src[keep], gt[keep]
             src_off = np.concatenate([[0], np.cumsum(np.where(use, ng, 0))])
-        H, _, found = cx.homography_batch(src, map_xy[gt_u], src_off, 0.1, seeds=np.arange(B) + i * B)
+        H, _, found = cx.homography_batch(src, xy_of(gt_u), src_off, 0.1, seeds=np.arange(B) + i * B)
         f.free()
         if record:
             with stats_lock:
                 stats["pyr_ms"].append(pyr_ms)
                 stats["knn_ms"].append(knn_ms)
                 stats["kp"].append(nq)
+                stats["q_launch"].append(sum(mt.last_counts) if (mt.world > 1 and not replicated_frames) else nq)
                 stats["good"].append(float(ng.mean()))
                 stats["found"] += int(found.sum())
         return H
@@ -402,40 +500,87 @@ def main():
     wall = time.perf_counter() - t0
     if world > 1:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        sharded.all_reduce(tw, dist.ReduceOp.MAX)
         wall = float(tw.item())
 
-    # N > 1, replicated map: the sharded-map exchange path, run AFTER the headline is final (see the watchdog below)
-    def sharded_map_extra():
-        try:
-            mt_sh = sharded.ShardedMatcher(ctx, f_shard, lo, dev)
-            n_sh = 10
-            # the exchange path must give what the whole map gives: one batch through both, compared bit for bit
-            f_chk, _ = ctx.sift_extract_batch_dev(batches_d[0].data_ptr(), B, 480 * 640, 480, 640, 640, params)
-            a = matcher.match_dp(f_chk, len(f_chk), bq_cap)
+    # ---- after the timed region -------------------------------------------------------------------------------------
+    knn_ms = float(np.mean(stats["knn_ms"]))
+    q_launch = float(np.mean(stats["q_launch"]))
+    achieved_tf = 256.0 * q_launch * n_local / (knn_ms * 1e-3) / 1e12     # 256 flop per (query, train) pair
+    multi = None
+    if world > 1:
+        # every rank's kNN launch (fraction of the bf16 MFMA peak), and the exchange alone: the step's collectives on
+        # buffers of the step's size, bracketed by events on the context's stream
+        mine = torch.tensor([achieved_tf / MFMA_BF16_PEAK_TF, knn_ms, q_launch, float(n_local)], dtype=torch.float64, device=dev)
+        allr = torch.empty((world, 4), dtype=torch.float64, device=dev)
+        sharded.all_gather(allr.view(-1), mine)
+        allr = allr.cpu().numpy()
+        ex_us = None
+        if workload != "c1":
+            nq_x = int(np.mean(stats["kp"]))
+            cap_x = bq_cap if B > 1 else q_cap
+            st = torch.cuda.ExternalStream(ctx.stream, device=dev)
+            reps = 20
+            with torch.cuda.stream(st):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if replicated_frames:
+                    a = torch.zeros((nq_x, 4), dtype=torch.int32, device=dev)
+                    b = torch.zeros((world * nq_x, 4), dtype=torch.int32, device=dev)
+                    sharded.all_gather(b, a)
+                    e0.record()
+                    for _ in range(reps):
+                        sharded.all_gather(b, a)
+                    e1.record()
+                else:
+                    a = torch.zeros((cap_x, 128), dtype=torch.uint8, device=dev)
+                    b = torch.zeros((world * cap_x, 128), dtype=torch.uint8, device=dev)
+                    c = torch.zeros((world * cap_x, 4), dtype=torch.int32, device=dev)
+                    d = torch.zeros((world * cap_x, 4), dtype=torch.int32, device=dev)
+                    sharded.all_gather(b, a)
+                    sharded.all_to_all(d, c)
+                    e0.record()
+                    for _ in range(reps):
+                        sharded.all_gather(b, a)
+                        sharded.all_to_all(d, c)
+                    e1.record()
+            e1.synchronize()
+            ex = torch.tensor([e0.elapsed_time(e1) / reps * 1e3], dtype=torch.float64, device=dev)
+            sharded.all_reduce(ex, dist.ReduceOp.MAX)
+            ex_us = float(ex.item())
+        # IMATCH_BENCH_VERIFY=1 (tests, rehearsals at small --map-rows): this rank also builds the WHOLE map and checks that
+        # the exchange path gave one batch exactly what a single launch over all rows gives
+        same_as_whole = None
+        if workload != "c1" and os.environ.get("IMATCH_BENCH_VERIFY") == "1":
+            whole = torch.empty((n_map, 128), dtype=torch.uint8, device=dev)
+            f_map.desc_u8_dev(whole.data_ptr())
+            ctx.synchronize()
+            if n_map > n_real:
+                whole[n_real:] = synth.synth_descriptors_dev(0, n_map - n_real, dev, seed=7)
+            torch.cuda.synchronize(dev)
+            f_whole = ctx.features_from_device_u8(whole.data_ptr(), n_map)
+            if B > 1:
+                f_chk, _ = ctx.sift_extract_batch_dev(batches_d[0].data_ptr(), B, 480 * 640, 480, 640, 640, params)
+            else:
+                f_chk = ctx.sift_extract_dev(frames_d[0].data_ptr(), 480, 640, 640, params)
+            a = match(matcher, f_chk, len(f_chk), bq_cap if B > 1 else q_cap)
             ctx.synchronize()
             a = a.clone()
-            b = mt_sh.match_dp(f_chk, len(f_chk), bq_cap)
+            b = torch.empty((len(f_chk), 4), dtype=torch.int32, device=dev)
+            ctx.knn2_dev(f_chk, f_whole, b.data_ptr())
             ctx.synchronize()
             same = torch.tensor([int(torch.equal(a, b))], dtype=torch.int64, device=dev)
-            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            sharded.all_reduce(same, dist.ReduceOp.MIN)
+            same_as_whole = bool(same.item())
             f_chk.free()
-            for i in range(2):
-                step_batch(i, False, 0, mt_sh)
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(n_sh):
-                step_batch(i, False, 0, mt_sh)
-            barrier()
-            tw = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            return {"frames_per_s": world * B * n_sh / float(tw.item()), "ms_per_step": float(tw.item()) / n_sh * 1e3,
-                    "steps": n_sh, "knn_launch_ms": ctx.knn2_kernel_ms(),
-                    "per_launch": "%d query rows (all ranks' batches, padded) x %d shard rows" % (world * bq_cap, hi - lo),
-                    "exchange": "all_gather of u8 query rows + all_to_all of per-shard top-2 (RCCL), merge_top2",
-                    "identical_to_whole_map": bool(same.item())}
-        except Exception as e:    # must not take the headline down with it
-            return {"error": repr(e)[:300]}
+            f_whole.free()
+            del whole
+        multi = {"identical_to_whole_map": same_as_whole, "per_rank_knn_frac": [float(v) for v in allr[:, 0]], "per_rank_knn_launch_ms": [float(v) for v in allr[:, 1]],
+                 "per_rank_queries_per_launch": [float(v) for v in allr[:, 2]], "per_rank_shard_rows": [int(v) for v in allr[:, 3]],
+                 "exchange_us_per_step": ex_us,
+                 "exchange": None if workload == "c1" else
+                             ("all_gather of per-shard top-2, 16 B per query and rank" if replicated_frames else
+                              "all_gather of u8 query rows (128 B per row) + all_to_all of per-shard top-2 (16 B per query and rank)"),
+                 "collective_backend": dist.get_backend(), "world_size_seen": dist.get_world_size()}
 
     # single-frame latency, outside the timed region: the per-frame calls, one frame at a time
     single_ms = None
@@ -450,101 +595,92 @@ def main():
         single_ms = (time.perf_counter() - t1) / 20 * 1e3
 
     gc.enable()
+    out = None
     if rank == 0:
-        fps = world * n_streams * B * args.steps / wall
+        frames_per_step = (1 if replicated_frames else world) * n_streams * B
+        fps = frames_per_step * args.steps / wall
         q_mean = float(np.mean(stats["kp"]))
-        knn_ms = float(np.mean(stats["knn_ms"]))
-        cap_rows = bq_cap if B > 1 else q_cap
-        exchange = world > 1 and map_mode == "sharded"
-        q_per_launch = (world * cap_rows) if exchange else q_mean     # one launch holds all B frames' keypoints
-        flops = 256.0 * q_per_launch * n_local            # 256 flop per (query, train) pair
-        achieved_tf = flops / (knn_ms * 1e-3) / 1e12
         pyr_bytes = PYRAMID_BYTES_PER_INPUT_PIXEL * args.map_side * args.map_side
+        what = {"c1": "640x480 gray frame vs full %dx%d synthetic orthomap, %d map descriptors resident in HBM (configs[1])"
+                      % (args.map_side, args.map_side, n_map),
+                "c3": "640x480 gray frames vs a %d-row descriptor map (the %dx%d orthomap's %d real rows + SURVEY 8(d) synthetic "
+                      "rows) sharded over %d GPU(s), RCCL top-2 merge (configs[3])" % (n_map, args.map_side, args.map_side, n_real, world),
+                "c5": "%d replicated 640x480 frames per step vs a %d-row descriptor map sharded over %d GPU(s), all-gather "
+                      "top-2 merge (configs[4])" % (B, n_map, world)}[workload]
+        par = {"c1": "single GPU" if world == 1 else "map replicated on %d GPUs, frames data-parallel, no collective" % world,
+               "c3": "map sharded x%d by contiguous row ranges, frames data-parallel (match_dp)" % world,
+               "c5": "map sharded x%d by contiguous row ranges, frames replicated (match_replicated)" % world}[workload]
         out = {
             "metric": "frames/sec (SIFT+kNN+RANSAC) vs map",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if replicated_frames else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "640x480 gray frame vs full %dx%d synthetic orthomap, %d map descriptors resident "
-                                   "in HBM (configs[1])" % (args.map_side, args.map_side, n_map),
+            "config": {"workload": what, "workload_id": workload,
                        "frame": "640x480 u8", "map_descriptors": n_map, "keypoints_per_frame": q_mean / B,
-                       "frames_per_step_per_gpu": B * n_streams,
+                       "frames_per_step_per_gpu": B * n_streams, "frames_per_step": frames_per_step,
                        "entry_points": "batched (imatch_sift_extract_batch_dev, one kNN launch, imatch_ratio_batch_dev, "
                                        "imatch_homography_batch)" if B > 1 else "single-frame",
                        "good_matches_per_frame": float(np.mean(stats["good"])),
                        "homographies_found": "%d/%d" % (stats["found"], args.steps * B * n_streams), "ratio": ratio,
-                       "frames_in_flight_per_gpu": n_streams,
-                       "parallelism": "single GPU" if world == 1 else
-                                      ("map sharded x%d, frames data-parallel" % world if exchange else
-                                       "map replicated on %d GPUs, frames data-parallel, no collective" % world)},
-            "knn_gdist_per_s": world * q_per_launch * float(n_local) / (knn_ms * 1e-3) / 1e9,
-            "roofline": {"kernel": ("knn2_kernel16<8,128> (bf16 MFMA 16x16x32, fused top-2)" if q_per_launch > 512
+                       "frames_in_flight_per_gpu": n_streams, "parallelism": par},
+            "knn_gdist_per_s": (world if multi else 1) * q_launch * float(n_local) / (knn_ms * 1e-3) / 1e9,
+            "roofline": {"kernel": ("knn2_kernel16 (bf16 MFMA 16x16x32, fused top-2)" if q_launch > 512
                                     else "knn2_kernel (bf16 MFMA 32x32x16, fused top-2)"), "bound": "mfma", "achieved": achieved_tf,
                          "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_BF16_PEAK_TF,
                          "traffic": None, "launch_ms": knn_ms,
-                         "per_launch": "%d queries x %d train rows x 256 flop" % (int(q_per_launch), n_local)},
+                         "per_launch": "%d queries x %d train rows x 256 flop%s" % (int(q_launch), n_local,
+                                                                                   " (rank 0's launch)" if world > 1 else "")},
             "roofline_pyramid": {"kernel": "scale-space stage of the %dx%d map extraction (upsample, blur+DoG, "
                                            "decimate, extrema scan)" % (args.map_side, args.map_side),
                                  "bound": "hbm", "achieved": pyr_bytes / (pyr_ms_map * 1e-3) / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": pyr_bytes / (pyr_ms_map * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                 "stage_ms": pyr_ms_map, "frame_stage_ms": float(np.mean(stats["pyr_ms"]))},
+                                 "stage_ms": pyr_ms_map, "frame_stage_ms": float(np.mean(stats["pyr_ms"])),
+                                 "bytes_moved": PYRAMID_BYTES_MOVED_PER_INPUT_PIXEL * args.map_side * args.map_side,
+                                 "frac_moved": PYRAMID_BYTES_MOVED_PER_INPUT_PIXEL * args.map_side * args.map_side
+                                               / (pyr_ms_map * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "achieved / frac: SURVEY 8(d)'s algorithmic 475.7 B per input pixel (counts DoG planes "
+                                         "written and re-read, which the kernels never store); frac_moved: the bytes the "
+                                         "kernels move (each blur reads and writes a layer once, the scan reads six layers, "
+                                         "the base blur reads the u8 image; PMC-confirmed, profiles/)"},
         }
-        # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes over this same command
-        # (profiles/r1_pmc.md); it is attached only when that measurement was taken on the same launch shape
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_knn.json")) as fh:
-                pmc = json.load(fh)
-            if world == 1 and B == pmc.get("batch", 32) and abs(pmc.get("n_queries", q_mean) - q_mean) < 0.05 * q_mean:
-                out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_note"] = "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE, " + pmc["source"]
-        except (OSError, ValueError, KeyError):
-            pass
+        if multi:
+            out["multi_gpu"] = multi
+        # HBM-side traffic of the dominant kernel: NOT measured in this run -- it comes from separate rocprofv3 --pmc passes
+        # over this same command, kept under profiles/, and is attached only when that measurement was taken on the
+        # same launch shape
+        for pmc_file in ("r2_pmc_knn.json", "r1_pmc_knn.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
+                    pmc = json.load(fh)
+                if workload == "c1" and world == 1 and B == pmc.get("batch", 32) and \
+                        abs(pmc.get("n_queries", q_mean) - q_mean) < 0.05 * q_mean:
+                    out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_note"] = ("from profiles/%s, not measured in this run: bytes per launch, "
+                                                       "2 x FETCH_SIZE + WRITE_SIZE, " % pmc_file) + pmc["source"]
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
         if single_ms is not None:
             out["single_frame"] = {"ms_per_frame": single_ms, "frames_per_s": 1e3 / single_ms,
                                    "note": "one frame at a time through the single-frame entry points, measured after "
                                            "the timed region; not part of value"}
-        if world == 1:
+        if world == 1 and workload == "c1":
             out["akaze_path"] = akaze_extra(ctx, map_img, ratio)
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
-            n_s = n_map if n_map <= 300_000 else 100_000
-            d_s = f_local.download(keypoints=False)[1][:n_s].astype(np.uint8)
-            out["cpu_baseline"], kept = cpu_baseline(frames_h[:16], d_s, n_map, map_xy[:n_s], ratio, threads)
-            if n_s == n_map:    # the oracle matched against the whole map: its lists are comparable as they are
+            if n_map == n_real and n_map <= 300_000:
+                d_s = f_local.download(keypoints=False)[1].astype(np.uint8)
+                xy_s = map_xy
+            else:   # the oracle's kNN leg runs against the first 100 000 rows and is scaled to the map (a dense scan)
+                d_s = f_map.download(keypoints=False)[1][:100_000].astype(np.uint8)
+                xy_s = map_xy[:100_000]
+            out["cpu_baseline"], kept = cpu_baseline(frames_h[:16], d_s, n_map, xy_s, ratio, threads)
+            if len(d_s) == n_map:    # the oracle matched against the whole map: its lists are comparable as they are
                 out["parity"] = parity_block(ctx, params, frames_h, truth_H, kept, f_local, map_xy, ratio)
         else:
             out["cpu_baseline"] = None
-    else:
-        out = None
-
-    # The headline is final here. At N > 1 with a replicated map the sharded-map loop runs now, under a watchdog: this
-    # is the only part of the run that depends on the all_gather / all_to_all exchange, and if it does not come back
-    # (every rank would then sit in the same collective) each rank's watchdog ends its process with status 0 after rank 0
-    # has printed the line without it.
-    printed = threading.Lock()
-
-    def emit(extra):
-        with printed:
-            if rank == 0 and out is not None and "_done" not in out:
-                if extra is not None:
-                    out["sharded_map"] = extra
-                out["_done"] = True
-                print(json.dumps({k: v for k, v in out.items() if k != "_done"}), flush=True)
-
-    if world > 1 and map_mode == "replicated" and B > 1 and os.environ.get("IMATCH_BENCH_SHARDED_EXTRA", "1") != "0":
-        finished = threading.Event()
-
-        def watchdog():
-            if not finished.wait(float(os.environ.get("IMATCH_BENCH_EXTRA_TIMEOUT", "120"))):
-                emit({"error": "the sharded-map loop did not finish in time; the headline does not depend on it"})
-                os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
-        extra = sharded_map_extra()
-        finished.set()
-        emit(extra)
-    else:
-        emit(None)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -60,6 +60,8 @@ SIGNATURES = {
     "imatch_features_from_host_f32": (ctypes.c_int, [c_vp, c_f32p, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_features_from_host_u8": (ctypes.c_int, [c_vp, c_u8p, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_features_from_device_u8": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "imatch_features_from_device_u8_seg": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.POINTER(c_i64), ctypes.c_size_t,
+                                                          ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_features_count": (c_i64, [c_vp]),
     "imatch_features_is_integral": (ctypes.c_int, [c_vp]),
     "imatch_features_free": (None, [c_vp]),
@@ -313,6 +315,16 @@ class Context:
             self._check(self.lib.imatch_features_from_device_u8(self._h, c_vp(dev_ptr), int(n), int(d),
                                                                 ctypes.byref(h)))
         return Features(self, h, n)
+
+    def features_from_device_u8_seg(self, dev_ptr, counts, seg_pitch_rows):
+        """One set from len(counts) row blocks in device memory: block b = counts[b] rows at dev_ptr + b * seg_pitch_rows
+        * 128 bytes (an all-gathered array of per-rank slots, each filled from its start). Queues work only."""
+        cnt = (c_i64 * len(counts))(*[int(c) for c in counts])
+        h = c_vp()
+        with self.lock:
+            self._check(self.lib.imatch_features_from_device_u8_seg(self._h, c_vp(dev_ptr), len(counts), cnt,
+                                                                    int(seg_pitch_rows) * 128, 128, ctypes.byref(h)))
+        return Features(self, h, sum(int(c) for c in counts))
 
     # -- pre-processing and SIFT ----------------------------------------------------------
     @staticmethod

@@ -874,6 +874,35 @@ int imatch_features_from_device_u8(imatch_ctx* ctx, const uint8_t* desc_dev, int
     return IMATCH_OK;
 }
 
+int imatch_features_from_device_u8_seg(imatch_ctx* ctx, const uint8_t* desc_dev, int n_seg, const int64_t* counts,
+                                       size_t seg_pitch, int d, imatch_features** out) {
+    if (!ctx || !out || !counts || n_seg < 1 || n_seg > IMATCH_MAX_BATCH)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "null argument or more than %d segments", IMATCH_MAX_BATCH);
+    if (d != IMATCH_DESC_DIM) return imatch_set_err(ctx, IMATCH_EINVAL, "descriptor dimension %d, need 128", d);
+    imatch_segtab seg;
+    memset(&seg, 0, sizeof(seg));
+    seg.n = n_seg;
+    int64_t total = 0;
+    for (int b = 0; b < n_seg; ++b) {
+        if (counts[b] < 0 || (size_t)counts[b] * 128 > seg_pitch)
+            return imatch_set_err(ctx, IMATCH_EINVAL, "segment %d: %lld rows do not fit its pitch of %zu bytes", b,
+                                  (long long)counts[b], seg_pitch);
+        total += counts[b];
+        if (total > (int64_t)INT_MAX - 2 * IMATCH_ROW_PAD) return imatch_set_err(ctx, IMATCH_ESIZE, "too many descriptors");
+        seg.off[b + 1] = (int)total;
+    }
+    if (total > 0 && !desc_dev) return imatch_set_err(ctx, IMATCH_EINVAL, "null descriptor pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    imatch_features* f = nullptr;
+    int rc = imatch_features_alloc(ctx, total, &f);
+    if (rc) return rc;
+    rc = imatch_features_pack_u8_seg_dev(ctx, f, desc_dev, &seg, seg_pitch);
+    if (rc) { imatch_features_free(f); return rc; }
+    *out = f;
+    return IMATCH_OK;
+}
+
 int imatch_features_desc_u8_dev(const imatch_features* f, uint8_t* out_dev) {
     if (!f) return IMATCH_EINVAL;
     imatch_ctx* ctx = f->ctx;

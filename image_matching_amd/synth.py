@@ -51,6 +51,64 @@ def synth_queries(train, nq, seed=8, noise=6, dup_frac=0.001):
     return q, src, dup
 
 
+# ---- the same descriptor statistics, generated on the device (BASELINE configs[3]/[4]: 5 M / 20 M rows) ---------------
+DEV_CHUNK = 1 << 18
+
+
+def synth_descriptors_dev(lo, hi, device, seed=7):
+    """Rows [lo, hi) of the SURVEY 8(d) descriptor map (Gamma(0.6, 1)^128, SIFT-normalised, u8) as a torch tensor on
+    `device`. Chunk c = rows [c*2^18, (c+1)*2^18) has its own generator seed, so any row range of the map -- a rank's
+    shard -- is generated without the rows before it and is the same on every rank. (numpy's Gamma sampler takes ~25 ns
+    per value: 5 M rows would cost a minute of host time per rank; the statistics are the same.)"""
+    import torch
+    out = torch.empty((hi - lo, 128), dtype=torch.uint8, device=device)
+    alpha = torch.full((DEV_CHUNK, 128), 0.6, dtype=torch.float32, device=device)
+    for c in range(lo // DEV_CHUNK, (max(hi, lo + 1) - 1) // DEV_CHUNK + 1):
+        g = torch.Generator(device=device).manual_seed(int(seed) * 1000003 + c)
+        v = torch._standard_gamma(alpha, generator=g)
+        nrm = v.square().sum(dim=1, keepdim=True).sqrt()
+        v = torch.minimum(v, 0.2 * nrm)
+        nrm2 = 512.0 / v.square().sum(dim=1, keepdim=True).sqrt().clamp_min(1.1920929e-07)
+        u = (v * nrm2).round().clamp(0, 255).to(torch.uint8)       # torch.round: half to even
+        a, b = max(lo, c * DEV_CHUNK), min(hi, (c + 1) * DEV_CHUNK)
+        if b > a:
+            out[a - lo:b - lo] = u[a - c * DEV_CHUNK:b - c * DEV_CHUNK]
+    return out
+
+
+def synth_queries_dev(train, nq, seed=8, noise=6, n_dup=0):
+    """Device version of synth_queries: queries = random rows of `train` (a u8 [n,128] torch tensor) + integer noise
+    U{-noise..noise}; the first n_dup queries are planted exactly at their source row AND at a higher row (exact ties at
+    distance 0: the lower index must rank first). `train` is modified in place. -> (queries u8 [nq,128], src int64 [nq],
+    dup int64 [nq], -1 where the query has no planted tie). Sources sit on even rows, duplicates on odd rows."""
+    import torch
+    n = train.shape[0]
+    g = torch.Generator(device=train.device).manual_seed(int(seed))
+    src = torch.randperm(max((n - 2) // 2, 1), device=train.device, generator=g)[:nq] * 2
+    if src.numel() < nq:      # more queries than even rows: repeat
+        src = src.repeat((nq + src.numel() - 1) // src.numel())[:nq]
+    q = train[src].to(torch.int16) + torch.randint(-noise, noise + 1, (nq, 128), dtype=torch.int16, device=train.device,
+                                                   generator=g)
+    q = q.clamp(0, 255).to(torch.uint8)
+    dup = torch.full((nq,), -1, dtype=torch.int64, device=train.device)
+    n_dup = min(n_dup, nq)
+    if n_dup > 0:
+        room = ((n - 1 - src[:n_dup]) // 2).clamp_min(1)                                     # odd offsets that stay inside
+        step = (torch.rand(n_dup, device=train.device, generator=g, dtype=torch.float64) * room).long().clamp_max(room - 1) * 2 + 1
+        hi_rows = src[:n_dup] + step
+        ok = hi_rows < n
+        # distinct sources on even rows, duplicates on odd rows: the two sets cannot collide; drop repeated odd rows
+        uniq = torch.ones_like(ok)
+        srt, order = torch.sort(hi_rows)
+        uniq[order[1:]] = srt[1:] != srt[:-1]
+        ok &= uniq
+        sel = torch.nonzero(ok).flatten()
+        train[src[sel]] = q[sel]
+        train[hi_rows[sel]] = q[sel]
+        dup[sel] = hi_rows[sel]
+    return q, src, dup
+
+
 # ---- images (SURVEY.md 8d: the reference's map.png and flight videos are not in its tree) -------
 def _upsample_bilinear(a, side):
     n = a.shape[0]

@@ -61,6 +61,13 @@ int imatch_features_from_host_f32(imatch_ctx* ctx, const float* desc, int64_t n,
 int imatch_features_from_host_u8(imatch_ctx* ctx, const uint8_t* desc, int64_t n, int d, imatch_features** out);
 /* Same, from a u8 [n][128] matrix already in device memory (a torch tensor's data_ptr). */
 int imatch_features_from_device_u8(imatch_ctx* ctx, const uint8_t* desc_dev, int64_t n, int d, imatch_features** out);
+/* Same, from n_seg (<= 64) row blocks in device memory: block b holds counts[b] rows of 128 bytes at
+ * desc_dev + b * seg_pitch bytes (the layout an all-gather of per-rank query blocks of a fixed capacity leaves: each
+ * rank's rows at the start of its slot). The set is the blocks' rows back to back, without the unused tail of any
+ * slot. Only queues work on the context's stream (u8 rows are integral by type: nothing to read back). No reference
+ * counterpart (multi-GPU path). */
+int imatch_features_from_device_u8_seg(imatch_ctx* ctx, const uint8_t* desc_dev, int n_seg, const int64_t* counts,
+                                       size_t seg_pitch, int d, imatch_features** out);
 /* Writes the set as u8 [n][128] into device memory (asynchronously, on the context's stream): the
  * exchange format of the multi-GPU path (queries are all-gathered as bytes). Integral sets only. */
 int imatch_features_desc_u8_dev(const imatch_features* f, uint8_t* out_dev);

@@ -37,3 +37,31 @@ def test_bench_line(capsys, monkeypatch):
     assert "error" not in p, p
     assert p["keypoints_within_0.5px"] >= 0.99 and p["knn_idx_and_dist_bit_exact"] and p["ratio_decisions_identical"]
     assert p["homography_corner_px_vs_oracle_max"] is None or p["homography_corner_px_vs_oracle_max"] <= 1.0
+
+
+def test_bench_launches_its_own_ranks_and_runs_the_sharded_map(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent starts both ranks itself, the headline workload is the
+    sharded map (configs[3] at a small --map-rows), and the exchange path gives what a single launch over the whole map
+    gives. Rehearsal form for a one-GPU box: both ranks on device 0, gloo in place of RCCL (which refuses two ranks on one
+    GPU); the code path is the one torchrun / the 8-GPU node runs."""
+    import subprocess
+    env = dict(os.environ, IMATCH_BENCH_DEVICE="0", IMATCH_BENCH_BACKEND="gloo", IMATCH_BENCH_VERIFY="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    for workload, scaling in (("c3", "weak"), ("c5", "strong")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                            "--map-side", "2048", "--map-rows", "150001", "--batch", "8", "--frames", "16", "--workload", workload],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["config"]["workload_id"] == workload
+        m = out["multi_gpu"]
+        assert m["world_size_seen"] == 2 and m["identical_to_whole_map"] is True
+        assert len(m["per_rank_knn_frac"]) == 2 and all(0 < f < 1 for f in m["per_rank_knn_frac"])
+        assert m["per_rank_shard_rows"] == [75001, 75000] and m["exchange_us_per_step"] > 0
+        frames = 8 * 2 * (2 if workload == "c3" else 1)
+        assert abs(out["value"] - frames / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+        found, total = out["config"]["homographies_found"].split("/")
+        assert int(found) >= 0.9 * int(total)

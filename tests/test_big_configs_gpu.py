@@ -1,0 +1,133 @@
+"""GPU parity at BASELINE.json's full sizes, through the C-ABI.
+
+configs[1]  CLAHE + SIFT on the whole 8192 x 8192 map against the oracle on the same image: every keypoint, in order.
+configs[3]  kNN 4096 queries x 5 M descriptors (the whole map of the 8-GPU layout on one GPU).
+configs[4]  kNN 131072 queries x 2.5 M descriptors (one of the eight shards of the 20 M-row map).
+            For both: SURVEY 8(d) descriptor statistics, planted exact ties (lowest index first), every reported
+            (index, ssd) pair recomputed from the rows, nobody may be worse than his own source row, an exact full-width
+            top-2 (f32 GEMM of integer rows: every sum is an integer below 2^24) for a sample of the queries, and the CPU
+            oracle on a window of <= 300 k rows."""
+import numpy as np
+import pytest
+
+import oracle
+from image_matching_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- configs[1] --------------------------------------------------------------------------------------------------------
+def _big_map():
+    """8192 x 8192 from four seeded 2048 x 2048 synthetic maps, turned and mirrored (the 8192^2 generator itself takes 12 s)."""
+    base = [synth.synth_map(2048, seed=40 + i) for i in range(4)]
+    rows = []
+    for r in range(4):
+        row = []
+        for c in range(4):
+            b = base[(r + c) % 4]
+            k = (r * 4 + c) % 8
+            b = np.rot90(b, k % 4)
+            row.append(b.T if k >= 4 else b)
+        rows.append(np.concatenate(row, axis=1))
+    return np.ascontiguousarray(np.concatenate(rows, axis=0))
+
+
+def test_sift_whole_8192_map_against_the_oracle(ctx):
+    """find_kp_dp's extraction (CLAHE + SIFT, match_finder.py:199-221) of the whole 8192 x 8192 map -- the large-image path:
+    16384^2 base octave, staggered layers, two streams, one wave per keypoint in the descriptor stage -- against the CPU
+    oracle on the same image (about 10 s on the box's host cores)."""
+    m = _big_map()
+    f = ctx.sift_extract(m)
+    kp, desc = f.download()
+    eq = ctx.clahe(m)
+    assert np.array_equal(eq, oracle.clahe(m))
+    res = oracle.sift(eq)
+    assert len(kp) > 150_000 and len(kp) == len(res.kp)
+    # same order, same positions, same packed octave | layer | xi field and response, bit for bit
+    assert np.array_equal(kp[:, :2], res.kp[:, :2])
+    assert np.array_equal(kp[:, 4:], res.kp[:, 4:])
+    assert np.abs(kp[:, 2] - res.kp[:, 2]).max() <= 1e-4                         # size: last place of an exp2f
+    dang = np.abs((kp[:, 3] - res.kp[:, 3] + 180.0) % 360.0 - 180.0)
+    assert dang.max() < 1.0 and np.percentile(dang, 99) < 1e-2                   # device atan2f / expf against glibc's
+    l2 = np.linalg.norm(desc - res.desc, axis=1)
+    assert (l2 <= 16).mean() >= 0.99 and (l2 == 0).mean() >= 0.995, ((l2 <= 16).mean(), (l2 == 0).mean(), l2.max())
+    f.free()
+
+
+# ---- configs[3] / configs[4] -----------------------------------------------------------------------------------------------
+def _ssd_rows(torch, q, t_rows):
+    d = q.to(torch.int32) - t_rows.to(torch.int32)
+    return (d * d).sum(dim=1)
+
+
+def _exact_top2(torch, q, t, block=1 << 20):
+    """Exact (ssd, idx) top-2 with the lowest-index tie-break over ALL rows of t for a few queries: f32 GEMM of integer
+    rows (exact: every partial sum is an integer below 2^24), first-occurrence minima."""
+    qf = q.to(torch.float32)
+    qn = (qf * qf).sum(dim=1)
+    best = torch.full((q.shape[0], 2), 2 ** 31 - 1, dtype=torch.int64, device=q.device)
+    bidx = torch.full((q.shape[0], 2), -1, dtype=torch.int64, device=q.device)
+    for s in range(0, t.shape[0], block):
+        tf = t[s:s + block].to(torch.float32)
+        d = (qn[:, None] + (tf * tf).sum(dim=1)[None, :] - 2.0 * (qf @ tf.T)).to(torch.int64)
+        for _ in range(2):
+            m, _unused = d.min(dim=1)
+            first = (d == m[:, None]).to(torch.int8).argmax(dim=1)       # first occurrence = lowest index
+            cand_d = torch.cat([best, m[:, None]], dim=1)
+            cand_i = torch.cat([bidx, (first + s)[:, None]], dim=1)
+            # order by (ssd, idx): idx of earlier blocks is lower, stable sort keeps them first on ties
+            order = torch.sort(cand_d, dim=1, stable=True).indices[:, :2]
+            best, bidx = torch.gather(cand_d, 1, order), torch.gather(cand_i, 1, order)
+            d[torch.arange(q.shape[0], device=q.device), first] = 2 ** 40
+    return best, bidx
+
+
+def _check_knn_at_scale(ctx, n, nq, n_dup, seed):
+    import torch
+    dev = torch.device("cuda:0")
+    t = synth.synth_descriptors_dev(0, n, dev, seed=7)
+    q, src, dup = synth.synth_queries_dev(t, nq, seed=seed, n_dup=n_dup)
+    ft = ctx.features_from_device_u8(t.data_ptr(), n)
+    fq = ctx.features_from_device_u8(q.data_ptr(), nq)
+    out4 = torch.empty((nq, 4), dtype=torch.int32, device=dev)
+    ctx.knn2_dev(fq, ft, out4.data_ptr())
+    ctx.synchronize()
+    o = out4.to(torch.int64)
+    # every reported pair is a real pair: ssd recomputed from the rows
+    assert (o[:, 1] >= 0).all() and (o[:, 3] >= 0).all() and (o[:, 1] != o[:, 3]).all()
+    assert torch.equal(_ssd_rows(torch, q, t[o[:, 1]]).to(torch.int64), o[:, 0])
+    assert torch.equal(_ssd_rows(torch, q, t[o[:, 3]]).to(torch.int64), o[:, 2])
+    assert (o[:, 0] <= o[:, 2]).all()
+    # nobody is worse than his own source row (noise of at most 6 per value: ssd <= 128 * 36)
+    own = _ssd_rows(torch, q, t[src]).to(torch.int64)
+    assert (o[:, 0] <= own).all() and (own <= 128 * 36).all()
+    # planted exact ties: (0, source) then (0, duplicate), lower index first
+    has = dup >= 0
+    assert int(has.sum()) >= n_dup // 2
+    assert (o[has, 0] == 0).all() and (o[has, 2] == 0).all()
+    assert torch.equal(o[has, 1], src[has]) and torch.equal(o[has, 3], dup[has])
+    # exact full-width answer for a sample of the queries (ties included)
+    pick = torch.cat([torch.nonzero(has).flatten()[:16], torch.arange(nq - 48, nq, device=dev)])
+    eb, ei = _exact_top2(torch, q[pick], t)
+    assert torch.equal(o[pick][:, [0, 2]], eb) and torch.equal(o[pick][:, [1, 3]], ei)
+    # the CPU oracle on a window of the map: the queries whose source lies in it, against those rows only
+    w0, w1 = n // 2, n // 2 + 200_000
+    inside = torch.nonzero((src >= w0) & (src < w1) & ((dup < 0) | (dup < w1))).flatten()[:256]
+    if len(inside):
+        fw = ctx.features_from_device_u8(t[w0:w1].data_ptr(), w1 - w0)
+        fqw = ctx.features_from_device_u8(q[inside].contiguous().data_ptr(), len(inside))
+        idx, dist = ctx.knn2(fqw, fw)
+        ridx, rdist = oracle.knn2(q[inside].cpu().numpy(), t[w0:w1].cpu().numpy(), threads=16)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+        fw.free()
+        fqw.free()
+    ft.free()
+    fq.free()
+
+
+def test_knn_config3_4096_queries_x_5M_rows(ctx):
+    _check_knn_at_scale(ctx, 5_000_000, 4096, 64, seed=8)
+
+
+def test_knn_config4_shard_131072_queries_x_2_5M_rows(ctx):
+    _check_knn_at_scale(ctx, 2_500_000, 131072, 512, seed=9)

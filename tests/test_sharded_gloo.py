@@ -47,6 +47,10 @@ class _FakeBackend:
     def features_from_device_u8(self, ptr, n, d=128):
         return _FakeFeatures(_view(ptr, (n, 128), np.uint8).copy())
 
+    def features_from_device_u8_seg(self, ptr, counts, seg_pitch_rows):
+        slots = _view(ptr, (len(counts), seg_pitch_rows, 128), np.uint8)
+        return _FakeFeatures(np.concatenate([slots[b, :c] for b, c in enumerate(counts)] + [np.zeros((0, 128), np.uint8)]))
+
     def knn2_dev(self, q, t, out_ptr, idx_offset=0):
         import oracle
         out = _view(out_ptr, (q.n, 4), np.int32)
@@ -107,6 +111,15 @@ def _worker(rank, world, port, ret):
         m_rep = sharded.ShardedMatcher(be, be.features(train), 0, "cpu", local_only=True)
         out3 = m_rep.match_dp(be.features(mine), len(mine), q_cap=256).numpy().copy()
         ok_local = m_rep.world == 1 and np.array_equal(out3, out2)
+        # ragged exchange: rank 1 sends no rows at all, rank 0 fills its slot to the brim; stale rows of the earlier,
+        # larger call are still in the slots and must not be matched
+        mine4 = queries[0][:256 if rank == 0 else 0] if len(queries[0]) >= 256 else np.repeat(queries[0], 2, 0)[:256 if rank == 0 else 0]
+        out4 = m.match_dp(be.features(mine4), len(mine4), q_cap=256).numpy().copy()
+        ok_ragged = out4.shape == (len(mine4), 4) and m.last_counts == [256, 0]
+        if len(mine4):
+            ridx4, _ = oracle.knn2(mine4, train)
+            ok_ragged = ok_ragged and np.array_equal(out4[:, [1, 3]], ridx4)
+        ok_dp = ok_dp and ok_ragged
         ret[rank] = (bool(ok_rep), bool(ok_dp and ok_local), out2.shape[0])
     finally:
         dist.destroy_process_group()
