@@ -91,7 +91,7 @@ template <int QB, int TN>
 __global__ void __launch_bounds__(256, 2)
 knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ thneg,
             int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi,
-            int* __restrict__ gthr) {
+            int* __restrict__ gthr, int stage0, int list0, int rot) {
     constexpr int STAGE_U4 = TN * 16 + TN / 4;   // uint4 per stage: TN rows x 256 B, then TN f32 (-|t|^2/2)
     constexpr int NT = TN / 32;                  // 32-row tiles per stage
     constexpr int ST_F = QB * 256;               // floats of top-2 state per wave: [QB][b1,b2,i1,i2][64]
@@ -107,10 +107,13 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
     // workgroups b and b+8 share an XCD (its L2): same train chunk, different query tiles
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int chunk = (j / nQt) * 8 + xcd;
-    const int qt = j % nQt;
     if (chunk >= nChunks) return;
-    const int s_begin = (int)((int64_t)nStages * chunk / nChunks);
-    const int s_end = (int)((int64_t)nStages * (chunk + 1) / nChunks);
+    // Every XCD walks the query tiles from a different start: a tile then meets its chunks one XCD after the other
+    // instead of on all eight at once, so only its FIRST chunk is scanned with loose bounds -- the others inherit the
+    // chip-wide words.
+    const int qt = (j % nQt + (rot ? (xcd * nQt) >> 3 : 0)) % nQt;
+    const int s_begin = stage0 + (int)((int64_t)nStages * chunk / nChunks);
+    const int s_end = stage0 + (int)((int64_t)nStages * (chunk + 1) / nChunks);
 
     // resident query fragments: lane holds q[row r][k = 16 ks + 8 h .. +7] = 16-byte chunk 2 ks + h
     const int64_t qrow0 = (int64_t)qt * (4 * 32 * QB) + wave * (32 * QB);
@@ -289,7 +292,7 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
     }
 
     // one partial list per (chunk, lane half)
-    const int64_t list = (int64_t)chunk * 2 + h;
+    const int64_t list = (int64_t)(list0 + chunk) * 2 + h;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int64_t o = list * Qpad + qrow0 + qb * 32 + r;
@@ -311,7 +314,7 @@ template <int QB, int TN, int XM>   // QB blocks of 16 queries per wave (8: 128 
 __global__ void __launch_bounds__(256, 2)
 knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ thneg,
               int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi,
-              int* __restrict__ gthr, int young, unsigned young_wg) {
+              int* __restrict__ gthr, int young, unsigned young_wg, int stage0, int list0, int rot) {
     static_assert(QB % 4 == 0, "thresholds are fetched 64 queries at a time");
     constexpr int STAGE_U4 = TN * 16 + TN / 4;
     constexpr int NT = TN / 16;                  // 16-row tiles per stage
@@ -324,10 +327,10 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
 
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int chunk = (j / nQt) * 8 + xcd;
-    const int qt = j % nQt;
     if (chunk >= nChunks) return;
-    const int s_begin = (int)((int64_t)nStages * chunk / nChunks);
-    const int s_end = (int)((int64_t)nStages * (chunk + 1) / nChunks);
+    const int qt = (j % nQt + (rot ? (xcd * nQt) >> 3 : 0)) % nQt;   // see knn2_kernel
+    const int s_begin = stage0 + (int)((int64_t)nStages * chunk / nChunks);
+    const int s_end = stage0 + (int)((int64_t)nStages * (chunk + 1) / nChunks);
 
     // resident query fragments: lane holds q[row r of block qb][k = 32 t + 8 q .. +7] = 16-byte chunk 4 t + q
     const int64_t qrow0 = (int64_t)qt * (4 * 16 * QB) + wave * (16 * QB);
@@ -486,7 +489,7 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
     if (q == 0) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            const int64_t o = (int64_t)chunk * Qpad + qrow0 + qb * 16 + r;
+            const int64_t o = (int64_t)(list0 + chunk) * Qpad + qrow0 + qb * 16 + r;
             pb[o] = make_float2(b1[qb], b2[qb]);
             pi[o] = make_int2(i1[qb], i2[qb]);
         }
@@ -621,7 +624,13 @@ __global__ void pack_rows_kernel(const T* __restrict__ src, int64_t n, int64_t n
         }
         a = (float)s[2 * lane];
         b = (float)s[2 * lane + 1];
-        bad = !(a >= 0.f && a <= 255.f && a == truncf(a)) || !(b >= 0.f && b <= 255.f && b == truncf(b));
+        // integer in 0..255? decided on the bit patterns: this file is built with -fno-honor-nans (the MFMA kernels' max
+        // trees), under which a float compare may not be relied on to reject a NaN
+        auto is_u8 = [](float v) {
+            const int i = (int)fminf(fmaxf(v, -1.f), 256.f);   // NaN -> one of the bounds or 0, never a match below
+            return i >= 0 && i <= 255 && (__float_as_uint((float)i) == __float_as_uint(v) || __float_as_uint(v) == 0x80000000u);
+        };
+        bad = !is_u8(a) || !is_u8(b);
     }
     const __bf16 ha = (__bf16)a, hb = (__bf16)b;
     const float ra = (float)ha, rb = (float)hb;
@@ -726,15 +735,6 @@ __global__ void unpack_rows_u8_kernel(const uint16_t* __restrict__ src, int64_t 
 }
 
 // ---- launch -------------------------------------------------------------------------------
-template <int QB, int TN>
-static void launch_knn(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int nQt, int nChunks,
-                       int64_t Qpad, float2* pb, int2* pi, int* gthr) {
-    const unsigned grid = (unsigned)(nQt * nChunks);
-    const int nStages = (int)(t->n_pad / TN);
-    hipLaunchKernelGGL((knn2_kernel<QB, TN>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)q->desc,
-                       (const uint4*)t->desc, t->hneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr);
-}
-
 // ---- scratch of the entry point that allocates nothing (imatch_knn2_noalloc_dev) -----------------------------------
 // The launcher's scratch -- one partial top-2 list per (train chunk, query) and three bound words per query -- normally
 // lives in the context's growable workspace (hipMalloc on growth). Callers that cannot allocate get it from this
@@ -793,18 +793,37 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     const int qtile = 4 * 32 * QB;
     const int64_t Qpad = q->n_pad;  // multiple of 1024, so of every qtile
     const int nQt = (int)((q->n + qtile - 1) / qtile);
-    const int nStages = (int)(t->n_pad / TNs);
-    // chunks: a multiple of 8 (one group per XCD); about two workgroups per CU slot; >= 4 stages per chunk
+    const int nStagesAll = (int)(t->n_pad / TNs);
     const int slots = 512;
-    // (rounded DOWN to a multiple of 8, so that the grid stays within two rounds of slots)
-    int nChunks = ((2 * slots + nQt - 1) / nQt / 8) * 8;
-    // ... and chunks of at most 16k rows (4 MB, one XCD's L2): the query tiles that share a chunk then
-    // re-read it from L2 however far apart they run, and the many short workgroups balance the tail
-    nChunks = std::max(nChunks, (int)((t->n_pad + 16383) / 16384 + 7) / 8 * 8);
-    nChunks = std::min(nChunks, 256);
-    if (nChunks > nStages / 4) nChunks = (nStages / 4 / 8) * 8;
-    if (nChunks < 8) nChunks = 8;
-    if (const char* e = getenv("IMATCH_KNN_CHUNKS")) nChunks = std::max(8, atoi(e) / 8 * 8);  // tuning override
+    // chunks of a range of stages: a multiple of 8 (one group per XCD); about two workgroups per CU slot; >= 4 stages each
+    auto pick_chunks = [&](int nStages) {
+        // (rounded DOWN to a multiple of 8, so that the grid stays within two rounds of slots)
+        int c = ((2 * slots + nQt - 1) / nQt / 8) * 8;
+        // ... and chunks of at most 16k rows (4 MB, one XCD's L2): the query tiles that share a chunk then
+        // re-read it from L2 however far apart they run, and the many short workgroups balance the tail
+        c = std::max(c, (int)(((int64_t)nStages * TNs + 16383) / 16384 + 7) / 8 * 8);
+        c = std::min(c, 256);
+        if (c > nStages / 4) c = (nStages / 4 / 8) * 8;
+        if (c < 8) c = 8;
+        if (const char* e = getenv("IMATCH_KNN_CHUNKS")) c = std::max(8, atoi(e) / 8 * 8);  // tuning override
+        return c;
+    };
+    // Optional SEED launch (IMATCH_KNN_SEED=<divisor>, off by default): the first rows of the map (at most 1/divisor of it,
+    // one round of short workgroups) matched by a launch of their own, whose chip-wide bound words stay in place for the
+    // main launch over the other rows. Meant for few query tiles, where a tile's workgroups all start at once from loose
+    // bounds; measured it LOSES (2951 x 236k: 0.184 -> 0.198 ms, 4096 x 5 M: 3.02 -> 3.04 ms, profiles/r2_knn_shapes.txt):
+    // the second launch's ramp costs more than the insertion-path blocks it saves. The rotated tile order (rot) is what
+    // helps where the grid runs in many rounds.
+    static const int seed_div = getenv("IMATCH_KNN_SEED") ? atoi(getenv("IMATCH_KNN_SEED")) : 0;
+    static const int rot_on = getenv("IMATCH_KNN_ROT") ? atoi(getenv("IMATCH_KNN_ROT")) : 1;
+    int seedStages = 0, seedChunks = 0;
+    if (seed_div > 1 && nQt <= 64 && nStagesAll >= 16 * seed_div) {
+        seedChunks = std::max(8, slots / nQt / 8 * 8);                       // one round of workgroup slots ...
+        seedStages = std::min(nStagesAll / seed_div, seedChunks * 8);        // ... of at most 8 stages each
+        seedChunks = std::max(8, std::min(seedChunks, seedStages / 4) / 8 * 8);
+    }
+    const int nStages = nStagesAll - seedStages;
+    int nChunks = pick_chunks(nStages);
     const int lists_per_chunk = use16 ? 1 : 2;   // the 16x16x32 kernel merges its four row quarters itself
     const size_t gbytes = ((size_t)Qpad * 12 + 255) & ~(size_t)255;   // three bounds per query
     if (ws) {   // a fixed scratch block: fewer, longer chunks until the partial lists fit
@@ -813,9 +832,13 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
         if (room < 8)
             return imatch_set_err(ctx, IMATCH_ESIZE, "%lld queries need %zu bytes of kNN scratch, the fixed block holds %zu "
                                   "(at most 262144 queries per call)", (long long)q->n, 8 * per_chunk + gbytes, ws_cap);
-        nChunks = std::min(nChunks, (int)(room / 8) * 8);
+        if ((size_t)(nChunks + seedChunks) > room) {
+            if (room < 16) seedStages = seedChunks = 0;
+            else seedChunks = std::min(seedChunks, 8);
+            nChunks = std::min(nChunks, (int)((room - seedChunks) / 8) * 8);
+        }
     }
-    const int64_t nLists = (int64_t)nChunks * lists_per_chunk;
+    const int64_t nLists = (int64_t)(nChunks + seedChunks) * lists_per_chunk;
     const size_t pbytes = (size_t)nLists * Qpad * 8;
     if (!ws) {
         int rc = imatch_ws_reserve(ctx, 2 * pbytes + gbytes);
@@ -827,20 +850,34 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     int* gthr = (int*)((char*)ws + 2 * pbytes);
     HIP_TRY(ctx, hipMemsetAsync(gthr, 0x7f, gbytes, ctx->stream));  // 0x7f7f7f7f = 3.39e38 as a float
     if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (use16) {
-        const unsigned grid = (unsigned)(nQt * nChunks);
-#define LAUNCH16(TN_, XM_) hipLaunchKernelGGL((knn2_kernel16<8, TN_, XM_>), dim3(grid), dim3(256), 0, ctx->stream, \
-        (const uint4*)q->desc, (const uint4*)t->desc, t->hneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr, young, young_wg)
-        if (small16)
-            hipLaunchKernelGGL((knn2_kernel16<4, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)q->desc,
-                               (const uint4*)t->desc, t->hneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr, young, young_wg);
-        else if (TNs == 128 && xmask == 3) LAUNCH16(128, 3);
-        else if (TNs == 128) LAUNCH16(128, 7);
-        else LAUNCH16(64, 3);
-#undef LAUNCH16
-    } else if (QB == 4) launch_knn<4, 64>(ctx, q, t, nQt, nChunks, Qpad, pb, pi, gthr);
-    else if (QB == 2) launch_knn<2, 64>(ctx, q, t, nQt, nChunks, Qpad, pb, pi, gthr);
-    else launch_knn<1, 64>(ctx, q, t, nQt, nChunks, Qpad, pb, pi, gthr);
+    // one launch per range of stages: (first stage, stages, chunks, first partial list)
+    auto launch = [&](int stage0, int nSt, int nCh, int list0) {
+        const unsigned grid = (unsigned)(nQt * nCh);
+        const int rot = rot_on && grid > 2u * slots;
+#define KARGS (const uint4*)q->desc, (const uint4*)t->desc, t->hneg, nQt, nCh, nSt, Qpad, pb, pi, gthr
+        if (use16) {
+            if (small16)
+                hipLaunchKernelGGL((knn2_kernel16<4, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
+                                   stage0, list0, rot);
+            else if (TNs == 128 && xmask == 3)
+                hipLaunchKernelGGL((knn2_kernel16<8, 128, 3>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
+                                   stage0, list0, rot);
+            else if (TNs == 128)
+                hipLaunchKernelGGL((knn2_kernel16<8, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
+                                   stage0, list0, rot);
+            else
+                hipLaunchKernelGGL((knn2_kernel16<8, 64, 3>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
+                                   stage0, list0, rot);
+        } else if (QB == 4)
+            hipLaunchKernelGGL((knn2_kernel<4, 64>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, stage0, list0, rot);
+        else if (QB == 2)
+            hipLaunchKernelGGL((knn2_kernel<2, 64>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, stage0, list0, rot);
+        else
+            hipLaunchKernelGGL((knn2_kernel<1, 64>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, stage0, list0, rot);
+#undef KARGS
+    };
+    if (seedStages > 0) launch(0, seedStages, seedChunks, 0);
+    launch(seedStages, nStages, nChunks, seedChunks);
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     hipLaunchKernelGGL(knn2_finish_kernel, dim3((unsigned)((q->n + 15) / 16)), dim3(256), 0, ctx->stream, pb, pi,
