@@ -753,6 +753,29 @@ refine_kernel(PyrTable T, const uint2* __restrict__ cand, const int* __restrict_
     }
 }
 
+// The descriptor stage's own atan2 / exp / sqrt: its samples only feed interpolation WEIGHTS (a last-place difference moves
+// a weight by 1e-7 of itself), so the library functions' special-case handling and correctly rounded square root -- 70 of
+// the 190 instructions of one sample -- are not needed there. Same minimax polynomial as the device library's atan2f
+// (|error| < 2e-7 rad), reciprocal instead of a scaled division; finite inputs only (pixel differences).
+__device__ __forceinline__ float atan2_deg_lean(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mx > 0.f ? mn * __builtin_amdgcn_rcpf(mx) : 0.f;
+    const float u = t * t;
+    float p = fmaf(u, 0.002642294391989708f, -0.015280019491910934f);
+    p = fmaf(u, p, 0.04149937257170677f);
+    p = fmaf(u, p, -0.07413642853498459f);
+    p = fmaf(u, p, 0.10605181753635406f);
+    p = fmaf(u, p, -0.14197120070457458f);
+    p = fmaf(u, p, 0.19992350041866302f);
+    p = fmaf(u, p, -0.3333311676979065f);
+    float a = fmaf(t, u * p, t);
+    a = ay > ax ? 1.5707963267948966f - a : a;
+    a = x < 0.f ? 3.141592653589793f - a : a;
+    a *= (float)(180.0 / M_PI);
+    return y < 0.f ? 360.f - a : a;
+}
+
 __device__ __forceinline__ float atan2_deg(float y, float x) {
     float a = atan2f(y, x) * (float)(180.0 / M_PI);
     if (a < 0) a += 360.f;
@@ -884,36 +907,58 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
         if (fabsf(ori - 360.f) < FLT_EPSILON) ori = 0.f;
         const float scl = size * 0.5f;
         const int px = __float2int_rn(ptx), py = __float2int_rn(pty);
-        float cos_t = cosf(ori * (float)(M_PI / 180));
-        float sin_t = sinf(ori * (float)(M_PI / 180));
+        // Everything up to the sample loop runs once per WAVE on values every lane shares -- a third of a frame keypoint's
+        // instructions before it was cut down: hardware sine / cosine (the angle in revolutions; the window's rotation is
+        // good to 1e-6 rad), reciprocals for the divisions, an integer square root with a two-sided fix-up for the radius
+        // clamp instead of a double-precision one, 32-bit remainders.
+        float cos_t = __builtin_amdgcn_cosf(ori * (1.0f / 360.0f));
+        float sin_t = __builtin_amdgcn_sinf(ori * (1.0f / 360.0f));
         const float bins_per_rad = n / 360.f;
         const float exp_scale = -1.f / (d * d * 0.5f);
         const float hist_width = 3.f * scl;
         int radius = __float2int_rn(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
-        radius = min(radius, (int)sqrt(((double)cols) * cols + ((double)rows) * rows));
-        cos_t /= hist_width;
-        sin_t /= hist_width;
+        {   // min(radius, (int)sqrt(cols^2 + rows^2)): the sum stays below 2^31 for layers up to 32768 x 32768
+            const unsigned v = (unsigned)cols * (unsigned)cols + (unsigned)rows * (unsigned)rows;
+            unsigned rt = (unsigned)__builtin_amdgcn_sqrtf((float)v);
+            while (rt * rt > v) --rt;
+            while ((rt + 1) * (rt + 1) <= v) ++rt;
+            radius = min(radius, (int)rt);
+        }
+        const float inv_hw = __builtin_amdgcn_rcpf(hist_width);
+        cos_t *= inv_hw;
+        sin_t *= inv_hw;
         const int side = 2 * radius + 1, total = side * side;
         // Lanes of one instruction must not sit on neighbouring pixels: those fall into the same spatial cell
         // and similar orientation bins, and same-address LDS atomics serialise (that was 2/3 of this kernel).
         // total is odd, so multiplying the sample number by a power of two is a bijection mod total; one near
         // 0.3*total sends consecutive lanes to different bands of the patch. Sums are fixed-point, so the
         // visiting order does not change a single bit of the result.
-        int spread = 1;
-        while (spread * 4 <= total) spread <<= 1;
+        const int spread = total >= 4 ? 1 << (31 - __clz(total >> 2)) : 1;   // the largest power of two <= total / 4
         // p = (q * spread) mod total, kept incrementally (q advances by GL: one add and a conditional subtract),
         // and p / side through the float reciprocal: (p + 0.5) / side is at least 0.5 / side away from an integer,
         // far more than the rounding of the product for any patch side that fits an image. The three integer
         // divisions per sample this replaces were a quarter of the kernel's instructions.
-        const unsigned step = (unsigned)(((unsigned long long)GL * (unsigned)spread) % (unsigned)total);
-        unsigned p = (unsigned)(((unsigned long long)gl * (unsigned)spread) % (unsigned)total);
-        const float inv_side = 1.0f / (float)side;
+        const unsigned step = ((unsigned)GL * (unsigned)spread) % (unsigned)total;   // GL * spread < 2^8 * total / 4: 32 bits do
+        unsigned p = ((unsigned)gl * (unsigned)spread) % (unsigned)total;
+        const float inv_side = __builtin_amdgcn_rcpf((float)side);
         // About half of the square's samples fall outside the rotated 4x4 grid. Testing and accumulating in one
         // loop leaves those lanes idle through the ~200 instructions of the accumulation; instead every wave
         // QUEUES the samples that pass the test (their index p, slots from ballot prefix counts) and runs the
         // accumulation on 64 queued samples at a time, all lanes busy. The fixed-point sums do not depend on the order.
         unsigned* const wq = queue[threadIdx.x >> 6];
         int n_q = 0;   // wave-uniform
+        // the keypoint, hence its layer, is the same for every lane of the wave: the layer becomes a buffer resource in
+        // scalar registers (base made wave-uniform explicitly, else the compiler wraps every load in a waterfall loop), a
+        // sample's four pixels are raw buffer loads at 32-bit byte offsets, one of them with an immediate
+        // (readfirstlane returns int: both halves go through unsigned, or a low half with bit 31 set smears over the high one)
+        const unsigned long long img_bits = (unsigned long long)img;
+        const unsigned img_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)img_bits);
+        const unsigned img_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(img_bits >> 32));
+        void* const img_u = (void*)(((unsigned long long)img_hi << 32) | (unsigned long long)img_lo);
+        const __amdgpu_buffer_rsrc_t img_rs = __builtin_amdgcn_make_buffer_rsrc(
+            img_u, 0, __builtin_amdgcn_readfirstlane(rows * cols * 4), 0x00020000);
+        const unsigned cols4 = (unsigned)cols * 4u;
+        unsigned long long* const hp = hist[wave];
         auto accumulate = [&](unsigned ps) {
             const int pi = (int)(((float)ps + 0.5f) * inv_side);
             const int i = pi - radius, j = (int)ps - pi * side - radius;
@@ -921,12 +966,16 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
             const float r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f;
             float cbin = c_rot + d / 2 - 0.5f;
-            const unsigned at = (unsigned)(py + i) * (unsigned)cols + (unsigned)(px + j);   // below 2^30 elements
-            const float dx = img[at + 1] - img[at - 1];
-            const float dy = img[at - (unsigned)cols] - img[at + (unsigned)cols];
-            const float w = expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-            float obin = (atan2_deg(dy, dx) - ori) * bins_per_rad;
-            const float mag = sqrtf(dx * dx + dy * dy) * w;
+            const unsigned at = ((unsigned)(py + i) * (unsigned)cols + (unsigned)(px + j)) * 4u - 4u;   // bytes, pixel x - 1
+            const float dx = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(img_rs, (int)(at + 8u), 0, 0)) -
+                             __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(img_rs, (int)at, 0, 0));
+            const float dy = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(img_rs, (int)(at + 4u - cols4), 0, 0)) -
+                             __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(img_rs, (int)(at + 4u + cols4), 0, 0));
+            const float w = __expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            float obin = (atan2_deg_lean(dy, dx) - ori) * bins_per_rad;
+            // the sums are kept in 2^-20 fixed point: the scale goes in here once (a power of two: every product below
+            // is the unscaled one times 2^20, bit for bit)
+            const float mag = __builtin_amdgcn_sqrtf(dx * dx + dy * dy) * w * FIX_SCALE;
             const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
             int o0 = (int)floorf(obin);
             rbin -= r0; cbin -= c0; obin -= o0;
@@ -940,8 +989,8 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
             const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
             const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
             const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-            unsigned long long* hp = hist[wave];
-#define HADD(off, val) atomicAdd(&hp[idx + (off)], (unsigned long long)(long long)__float2int_rn((val) * FIX_SCALE))
+            // every term is >= 0 (a magnitude times fractions in [0, 1)) and below 2^31: unsigned, high word zero
+#define HADD(off, val) atomicAdd(&hp[idx + (off)], (unsigned long long)__float2uint_rn(val))
             HADD(0, v_rco000); HADD(1, v_rco001);
             HADD(n + 2, v_rco010); HADD(n + 3, v_rco011);
             HADD((d + 2) * (n + 2), v_rco100); HADD((d + 2) * (n + 2) + 1, v_rco101);
@@ -1515,9 +1564,18 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                                           (size_t)batch, hipMemcpyHostToDevice, ctx->stream));
             rc = imatch_hs_mark_busy(ctx);
             if (rc) { imatch_features_free(f); return rc; }
-            if (max_k <= 65536)
+            // Four waves per keypoint everywhere, the 236 k keypoints of an 8192^2 map included: with one wave per keypoint
+            // (four keypoints of different window sizes per workgroup) the map's launch took 3.15 ms against 2.4 ms, a
+            // 64-frame batch 2.2 ms against 1.7 ms -- the waves of a workgroup finish together when they share a keypoint.
+            // IMATCH_DESC_WPK = 1 / 2 keeps the other forms for A/B runs.
+            static const int wpk_env = getenv("IMATCH_DESC_WPK") ? atoi(getenv("IMATCH_DESC_WPK")) : 0;
+            const int wpk = wpk_env ? wpk_env : 4;
+            if (wpk == 4)
                 hipLaunchKernelGGL(describe_kernel<4>, dim3(max_k, 1, batch), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted,
                                    seg, first_octave, d_desc, zs);
+            else if (wpk == 2)
+                hipLaunchKernelGGL(describe_kernel<2>, dim3((max_k + 1) / 2, 1, batch), dim3(256), 0, ctx->stream, T,
+                                   (const KpRec*)d_sorted, seg, first_octave, d_desc, zs);
             else
                 hipLaunchKernelGGL(describe_kernel<1>, dim3((max_k + 3) / 4, 1, batch), dim3(256), 0, ctx->stream, T,
                                    (const KpRec*)d_sorted, seg, first_octave, d_desc, zs);
