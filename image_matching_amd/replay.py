@@ -32,6 +32,7 @@ DEFAULT_CONFIG = {
     "low_pass_speed": 60.0,
     "low_pass_coordinates": 60.0,
     "use_gps": True,
+    "use_baro": False,                              # True: the height follows the barometer relative to its first value (:595-603)
     "height": 500.0,
     "link_window_upscale": 2.0,
     "unlink_time_for_upscale": 5.0,
@@ -92,6 +93,9 @@ class PositionFinder:
         self.low_pass_coordinates = cfg["low_pass_coordinates"]
         self.use_gps = cfg["use_gps"]
         self.height = cfg["height"]
+        self.use_baro = cfg["use_baro"]
+        self.height_init = not self.use_baro         # position_finder.py:118-125
+        self.start_height = 0.0
         self.link_window_upscale = cfg["link_window_upscale"]
         self.unlink_time_for_upscale = cfg["unlink_time_for_upscale"]
         # what the node would publish / log
@@ -102,7 +106,18 @@ class PositionFinder:
         self.calls = {"frame_extract": 0, "roi_extract": 0, "find_matches": 0, "find_keypoints_transform": 0}
 
     # ---- photo_cb (position_finder.py:159-224) ---------------------------------------------------------
-    def photo_cb(self, image, imu=(0.0, 0.0, 0.0), gps=None, stamp=None):
+    def baro_cb(self, value):
+        """position_finder.py:595-603 for a replay (realtime False): height = barometer - its first value."""
+        if self.height_init is False:
+            self.height_init = True
+            self.start_height = value
+        self.height = value - self.start_height
+
+    def photo_cb(self, image, imu=(0.0, 0.0, 0.0), gps=None, stamp=None, baro=None):
+        if baro is not None and self.use_baro is True:
+            self.baro_cb(baro)
+        if self.use_baro is True and self.height_init is False:      # no height yet: the frame is dropped (:163)
+            return None
         self.now = float(stamp) if stamp is not None else self.now + 0.2
         self._frame = {"stamp": self.now, "good": 0, "roi_kp": 0, "cadr_kp": 0, "from_privyazka": False, "answer": None}
         self.frames.append(self._frame)
@@ -277,3 +292,105 @@ class PositionFinder:
             return False
         self.low_pass_time = self.now
         return True
+
+
+# ---- replay feeder: a frames directory + the telemetry CSV -----------------------------------------
+def parse_telemetry_csv(path):
+    """The flight log the reference replays beside a video (csv_data_pkg/src/csv_data_pkg/publish_csv.py:26-40; sample
+    csv_data_pkg/map/logs/log_1.csv): `;`-separated, one header row `time;lat;lon;alt;roll;pitch;head;ub;nsat`, time as
+    H:MM:SS.ss. -> float64 [n, 9] = seconds (h*3600 + m*60 + s, as __parse_time_to_sec), lat, lon, alt, roll, pitch, head
+    (degrees), ub, nsat."""
+    import csv
+    rows = []
+    with open(path, newline="") as fh:
+        for i, line in enumerate(csv.reader(fh, delimiter=";", quotechar="|")):
+            if i == 0 or not line:
+                continue
+            h, m, sec = (float(v) for v in line[0].split(":"))
+            rows.append([h * 3600 + m * 60 + sec] + [float(v) for v in line[1:9]])
+    return np.asarray(rows, dtype=np.float64).reshape(-1, 9)
+
+
+class Flight:
+    """A recorded flight as the reference's replay nodes feed it to position_finder: the frames of a video (here: a
+    directory of image files, one per video frame, in name order) published at photo_publisher's cadence, each with the
+    telemetry row that publish_csv would have sent last.
+
+    photo_publisher.py:107-132 reads one video frame per loop at `rate = fps * rate_multiplier` Hz and publishes the frame
+    of every loop in which its counter has passed rate / 5 (the counter then starts again): every sixth video frame at 25 fps,
+    4.2 frames per second of replay, gray (cvtColor BGR2GRAY). publish_csv.py:41-48 sends row i at (t_i - t_0) / rate_multiplier seconds after
+    the start, angles turned into radians (:53-57), altitude also as the barometer value (:75-76). Both clocks scale
+    with rate_multiplier, so in VIDEO time frame k sits at k / fps and row i at t_i - t_0, which is what `messages`
+    works in; a frame carries the last row at or before its time (the subscribers keep the latest message)."""
+
+    def __init__(self, frame_paths, telemetry=None, fps=25.0, rate_multiplier=1.0, ctx=None):
+        self.paths = list(frame_paths)
+        self.telemetry = np.zeros((0, 9)) if telemetry is None else np.asarray(telemetry, dtype=np.float64).reshape(-1, 9)
+        self.fps = int(fps)                      # int(cap.get(CAP_PROP_FPS)), photo_publisher.py:80
+        self.rate = self.fps * rate_multiplier   # :81
+        self.ctx = ctx
+
+    @classmethod
+    def from_dir(cls, frames_dir, telemetry_csv=None, fps=25.0, rate_multiplier=1.0, ctx=None,
+                 extensions=(".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff", ".pgm", ".npy")):
+        import os
+        names = sorted(n for n in os.listdir(frames_dir) if n.lower().endswith(extensions))
+        if telemetry_csv is None:               # photo_publisher looks for <video>.csv beside the video (:185-193)
+            cand = frames_dir.rstrip("/") + ".csv"
+            telemetry_csv = cand if os.path.exists(cand) else None
+        tel = parse_telemetry_csv(telemetry_csv) if telemetry_csv is not None else None
+        return cls([os.path.join(frames_dir, n) for n in names], tel, fps, rate_multiplier, ctx)
+
+    def published_indices(self):
+        """Indices of the video frames photo_publisher publishes (its counter logic, :109-132)."""
+        out, iterator = [], 0
+        for k in range(len(self.paths)):
+            if iterator > self.rate / 5:
+                out.append(k)
+                iterator = 0
+            iterator += 1
+        return out
+
+    def _gray(self, path):
+        if path.lower().endswith(".npy"):
+            img = np.load(path)
+        else:
+            from PIL import Image
+            with Image.open(path) as im:
+                img = np.asarray(im if im.mode in ("L", "RGB") else im.convert("RGB"))
+        if img.ndim == 2:
+            return np.ascontiguousarray(img, dtype=np.uint8)
+        # cv2.imread / VideoCapture hand out BGR and the node converts BGR2GRAY (:112); a file decoded as RGB is the same
+        # picture with the channels the other way round: the RGB form of the conversion gives the same gray values
+        from .utils import default_context
+        ctx = self.ctx if self.ctx is not None else default_context()
+        return ctx.cvt_gray(np.ascontiguousarray(img[:, :, :3], dtype=np.uint8), rgb=True)
+
+    def messages(self):
+        """Yields dict(stamp, image, imu=(roll, pitch, yaw) in radians, gps=(lat, lon) or None, baro or None, nsat, index)
+        for every published frame, in order."""
+        tel = self.telemetry
+        t_rel = tel[:, 0] - tel[0, 0] if len(tel) else np.zeros(0)
+        for k in self.published_indices():
+            stamp = k / float(self.fps)
+            row = None
+            if len(tel):
+                j = int(np.searchsorted(t_rel, stamp, side="right")) - 1
+                row = tel[j] if j >= 0 else None
+            msg = {"stamp": stamp, "index": k, "image": self._gray(self.paths[k]), "imu": (0.0, 0.0, 0.0), "gps": None,
+                   "baro": None, "nsat": None}
+            if row is not None:
+                msg["imu"] = tuple(float(v) / 180.0 * np.pi for v in row[4:7])
+                msg["gps"] = (float(row[1]), float(row[2]))
+                msg["baro"] = float(row[3])
+                msg["nsat"] = int(row[8])
+            yield msg
+
+    def run(self, position_finder, limit=None):
+        """Feed the flight to a PositionFinder (its photo_cb per published frame); returns the answers."""
+        out = []
+        for n, m in enumerate(self.messages()):
+            if limit is not None and n >= limit:
+                break
+            out.append(position_finder.photo_cb(m["image"], imu=m["imu"], gps=m["gps"], stamp=m["stamp"], baro=m["baro"]))
+        return out

@@ -177,3 +177,105 @@ def test_flight_against_the_resident_map_database(ctx):
                     for f in pf.fixes])
     assert err.max() < 0.5, err            # 1 map pixel
     db.release()
+
+
+# ---- replay feeder: frames directory + telemetry CSV (publish_csv.py:26-83, photo_publisher.py:107-132) ---------------
+def _write_flight_dir(tmp_path, n_frames, rows):
+    from PIL import Image
+    d = tmp_path / "flight_001"
+    d.mkdir()
+    for k in range(n_frames):
+        Image.fromarray(np.full((6, 8), k % 256, np.uint8)).save(d / ("frame_%05d.png" % k))
+    with open(str(d) + ".csv", "w") as fh:
+        fh.write("time;lat;lon;alt;roll;pitch;head;ub;nsat\n")
+        for r in rows:
+            fh.write(";".join(str(v) for v in r) + "\n")
+    return str(d)
+
+
+def test_telemetry_csv_is_parsed_like_publish_csv(tmp_path):
+    d = _write_flight_dir(tmp_path, 1, [("0:00:00.29", 45.043066, 37.387727, 624.526, 0.0, 0.0, 0.0, 0, 0),
+                                        ("1:02:03.50", 45.1, 37.2, 630.0, 1.5, -2.0, 90.0, 12, 7)])
+    tel = replay.parse_telemetry_csv(d + ".csv")
+    assert tel.shape == (2, 9)
+    assert tel[0, 0] == pytest.approx(0.29) and tel[1, 0] == pytest.approx(3600 + 2 * 60 + 3.5)     # __parse_time_to_sec
+    assert tuple(tel[1, 1:]) == (45.1, 37.2, 630.0, 1.5, -2.0, 90.0, 12.0, 7.0)
+    # the reference's own sample log has this layout (csv_data_pkg/map/logs/log_1.csv:1-5): header, then such rows
+    assert tuple(tel[0, 1:4]) == (45.043066, 37.387727, 624.526)
+
+
+def test_flight_from_dir_cadence_and_latest_telemetry(tmp_path):
+    rows = [("0:00:10.%02d" % 0, 55.0, 37.0, 100.0, 0.0, 0.0, 0.0, 0, 5)]
+    rows += [("0:00:%05.2f" % (10 + 0.5 * i), 55.0 + 1e-4 * i, 37.0, 100.0 + i, 1.0 * i, 0.0, 10.0 * i, 0, 5 + i) for i in range(1, 8)]
+    d = _write_flight_dir(tmp_path, 60, rows)
+    fl = replay.Flight.from_dir(d, fps=25.0)                         # the CSV beside the directory is found by name
+    # photo_publisher's counter: a frame goes out when the counter has passed rate / 5 = 5, i.e. at 6; it is then set to 0 and
+    # incremented in the same loop, so the next one follows six loops later (photo_publisher.py:109-131): 4.2 frames per
+    # second of video at 25 fps
+    assert fl.published_indices() == list(range(6, 60, 6))
+    msgs = list(fl.messages())
+    assert [m["index"] for m in msgs] == list(range(6, 60, 6)) and msgs[0]["stamp"] == pytest.approx(6 / 25.0)
+    assert all(m["image"].shape == (6, 8) and m["image"].dtype == np.uint8 and int(m["image"][0, 0]) == m["index"] for m in msgs)
+    # frame at 0.24 s carries row 0 (rows are at 0, 0.5, 1.0 ... s after the first); frame 30 (1.2 s) carries row 2
+    assert msgs[0]["gps"] == (55.0, 37.0) and msgs[0]["nsat"] == 5
+    m31 = [m for m in msgs if m["index"] == 30][0]
+    assert m31["gps"] == (pytest.approx(55.0002), 37.0) and m31["baro"] == 102.0
+    assert m31["imu"] == (pytest.approx(2.0 / 180 * np.pi), 0.0, pytest.approx(20.0 / 180 * np.pi))   # degrees -> radians
+    # a faster replay publishes fewer video frames per second of video (rate = fps * multiplier)
+    assert replay.Flight.from_dir(d, fps=25.0, rate_multiplier=2.0).published_indices() == list(range(11, 60, 11))
+
+
+def test_flight_feeds_the_position_finder_with_baro_height(tmp_path):
+    rows = [("0:00:00.00", 55.0, 37.0, 600.0, 0.0, 0.0, 0.0, 0, 9), ("0:00:01.00", 55.0, 37.0, 850.0, 0.0, 0.0, 30.0, 0, 9)]
+    d = _write_flight_dir(tmp_path, 40, rows)
+    mt = ScriptedMatcher(n_good=50)
+    pf = replay.PositionFinder(_map(), mt, {"count_of_pictures_for_odometry": 1e9, "use_baro": True})
+    answers = replay.Flight.from_dir(d, fps=25.0).run(pf)
+    assert len(answers) == 6 and all(a is True for a in answers)
+    # height = barometer - its first value (position_finder.py:595-603): 0 until the second row arrives, then 250
+    assert pf.start_height == 600.0 and pf.height == 250.0
+    assert pf.imu_yaw == pytest.approx(30.0 / 180 * np.pi) and (pf.lat_gps, pf.lon_gps) == (55.0, 37.0)
+    assert [f["stamp"] for f in pf.frames] == pytest.approx([k / 25.0 for k in range(6, 40, 6)])
+
+
+@pytest.mark.gpu
+def test_flight_read_from_a_frames_directory_fixes_match_truth(ctx, tmp_path):
+    """The whole feeder on the GPU path: colour frame files + telemetry CSV on disk -> Flight.from_dir -> PositionFinder.
+    One file per video frame at 25 fps; the publisher's cadence picks every sixth; every published frame must be fixed
+    within one map pixel of where its telemetry row says it was taken."""
+    from PIL import Image
+    from image_matching_amd.match_finder import match_finder
+    m = synth.synth_map(4096, seed=99)
+    n_pub = 5
+    flight = synth.synth_flight(m, n_pub, map_pixel_size=0.5, frame_pixel_size=0.375, fps=25.0 / 6, seed=3)
+    main_map = replay.make_map(m, 0.5)
+    g = replay.GeodeticConvert()
+    g.initialiseReference(main_map.main_points[0].lat, main_map.main_points[0].lon, 0)
+    d = tmp_path / "video_7"
+    d.mkdir()
+    rows, truth = [], {}
+    blank = np.zeros((720, 1280, 3), np.uint8)
+    for k in range(6 * n_pub + 1):
+        pub = k >= 6 and k % 6 == 0
+        img = blank
+        if pub:
+            f, tr = flight[k // 6 - 1]
+            img = np.repeat(f[:, :, None], 3, axis=2)                 # a gray picture stored as a colour file
+            lat, lon, _ = g.ned2Geodetic(north=-tr["cy"] * 0.5, east=tr["cx"] * 0.5, down=0)
+            t = k / 25.0
+            rows.append("0:00:%05.2f;%.9f;%.9f;500.0;0.0;0.0;%.6f;0;9" % (t + 5.0, lat, lon, tr["yaw"] * 180 / np.pi))
+            truth[k] = tr
+        Image.fromarray(img).save(d / ("f_%04d.png" % k), compress_level=1)
+    with open(str(d) + ".csv", "w") as fh:
+        fh.write("time;lat;lon;alt;roll;pitch;head;ub;nsat\n0:00:05.00;0;0;500.0;0;0;0;0;0\n" + "\n".join(rows) + "\n")
+    fl = replay.Flight.from_dir(str(d), fps=25.0, ctx=ctx)
+    assert fl.published_indices() == [6 * (i + 1) for i in range(n_pub)]
+    mf = match_finder(ctx)
+    mf.draw_matches = False
+    poi = replay.DEFAULT_CONFIG["camera_poi"] / 180.0 * np.pi
+    pf = replay.PositionFinder(main_map, mf, {"height": 0.375 * 1280 / (2 * np.tanh(poi / 2)), "low_pass_coordinates": 1e6})
+    answers = fl.run(pf)
+    assert answers == [True] * n_pub and len(pf.fixes) == n_pub, (answers, pf.errors[:2])
+    for fix, k in zip(pf.fixes, fl.published_indices()):
+        tr = truth[k]
+        assert np.hypot(fix["x_m"] - tr["cx"] * 0.5, fix["y_m"] - tr["cy"] * 0.5) < 1.0
