@@ -182,9 +182,12 @@ class Features:
         """-> float32 [n,2]: (x, y) of the given keypoint rows (kp[m.queryIdx].pt of match_finder.py:231-232)."""
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         out = np.empty((len(rows), 2), np.float32)
-        with self.ctx.lock:
-            self.ctx._check(self.ctx.lib.imatch_features_keypoints_xy(
-                self._h, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(rows), _ptr(out, c_f32p)))
+        # reads the set's own host-side keypoint table only: no device work, no context state, so no context lock (another
+        # thread may sit in a long call on the context meanwhile); the caller keeps the set alive
+        rc = self.ctx.lib.imatch_features_keypoints_xy(
+            self._h, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(rows), _ptr(out, c_f32p))
+        if rc != 0:
+            raise ImatchError("imatch error %d: keypoint rows out of range or a set without keypoints" % rc)
         return out
 
     def desc_u8_dev(self, out_ptr):

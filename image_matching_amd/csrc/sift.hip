@@ -1526,14 +1526,15 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         rc = imatch_features_alloc(ctx, Ktot, &f);
         if (rc) return rc;
         f->kp = (float*)malloc(sizeof(float) * 7 * (size_t)std::max(Ktot, 1));
-        for (int b = 0; b < batch; ++b) {
+        auto fill_table = [&](int b) {
             const KpRec* rec = h_kp + (size_t)b * kp_hint;
             for (int i = 0; i < seg.off[b + 1] - seg.off[b]; ++i) {
                 float* p = f->kp + 7 * (size_t)(seg.off[b] + i);
                 p[0] = rec[i].x; p[1] = rec[i].y; p[2] = rec[i].size; p[3] = rec[i].angle; p[4] = rec[i].response;
                 p[5] = (float)rec[i].octave; p[6] = -1.f;
             }
-        }
+        };
+
         const double t_d = now_ms();
         if (timing)
             fprintf(stderr, "[imatch] extract host phases: wait for GPU %.3f ms, sort %.3f ms, alloc + keypoint table %.3f ms\n",
@@ -1584,6 +1585,11 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // bf16 rows + norms of the concatenated set, queued (u8 rows are integral by type)
         rc = batch == 1 ? imatch_features_pack_u8_dev(ctx, f, d_desc) : imatch_features_pack_u8_seg_dev(ctx, f, d_desc, &seg, zs);
         if (rc) { imatch_features_free(f); return rc; }
+        // the host copy of the keypoint table is written while the GPU works on the descriptors (it reads the pinned rows
+        // the upload queued above is reading too)
+        if (batch >= 4) imatch_parallel_for(ctx, batch, fill_table);
+        else
+            for (int b = 0; b < batch; ++b) fill_table(b);
         *out = f;
         return IMATCH_OK;
     }

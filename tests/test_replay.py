@@ -263,7 +263,8 @@ def test_flight_read_from_a_frames_directory_fixes_match_truth(ctx, tmp_path):
             img = np.repeat(f[:, :, None], 3, axis=2)                 # a gray picture stored as a colour file
             lat, lon, _ = g.ned2Geodetic(north=-tr["cy"] * 0.5, east=tr["cx"] * 0.5, down=0)
             t = k / 25.0
-            rows.append("0:00:%05.2f;%.9f;%.9f;500.0;0.0;0.0;%.6f;0;9" % (t + 5.0, lat, lon, tr["yaw"] * 180 / np.pi))
+            # the row goes out 10 ms before the frame it belongs to is read (a frame carries the LATEST row)
+            rows.append("0:00:%05.2f;%.9f;%.9f;500.0;0.0;0.0;%.6f;0;9" % (t + 5.0 - 0.01, lat, lon, tr["yaw"] * 180 / np.pi))
             truth[k] = tr
         Image.fromarray(img).save(d / ("f_%04d.png" % k), compress_level=1)
     with open(str(d) + ".csv", "w") as fh:
