@@ -229,7 +229,7 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
         // Insertion path (rare, wave-uniform entry). Rows are visited in ascending train index with
         // strict <: OpenCV's lowest-index tie-break.
         auto epilogue = [&](const f32x16& a, int qb, int tile) {
-            if (__builtin_amdgcn_ballot_w64(max16(a) >= G[qb])) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(max16(a) >= G[qb]) != 0, 0)) {   // rare: hot path = fall-through
                 float* sq = st + qb * 256;
                 float b1 = sq[lane], b2 = sq[64 + lane];
                 int i1 = __float_as_int(sq[128 + lane]), i2 = __float_as_int(sq[192 + lane]);
@@ -430,7 +430,7 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
         };
         auto epilogue = [&](const f32x4& a, int qb, int tile) {
             const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-            if (__builtin_amdgcn_ballot_w64(m >= G[qb])) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= G[qb]) != 0, 0)) {   // rare: keep the hot path the fall-through
                 int rowbase = s * TN + tile * 16 + 4 * q;
                 asm volatile("" : "+v"(rowbase));
                 const float g = G[qb];
