@@ -310,12 +310,28 @@ knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const fl
 // 2.09 GHz by GRBM_GUI_ACTIVE), which is the reason for this variant.
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+#ifdef KNN_TRACE   // development only (tools/dbg/knn_trace.py): per-workgroup wall-clock stamps (100 MHz)
+#define KNN_TRACE_SLOTS 40
+__device__ long long knn_trace[2048 * KNN_TRACE_SLOTS];
+#define KT(slot) do { if (threadIdx.x == 0 && blockIdx.x < 2048 && (slot) < KNN_TRACE_SLOTS) \
+        knn_trace[blockIdx.x * KNN_TRACE_SLOTS + (slot)] = (long long)wall_clock64(); } while (0)
+extern "C" int imatch_dbg_knn_trace(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(knn_trace), sizeof(long long) * 2048 * KNN_TRACE_SLOTS);
+}
+#else
+#define KT(slot) do {} while (0)
+#endif
+
 template <int QB, int TN, int XM>   // QB blocks of 16 queries per wave (8: 128 queries, 512 per workgroup as above)
 __global__ void __launch_bounds__(256, 2)
 knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ thneg,
               int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi,
               int* __restrict__ gthr, int young, unsigned young_wg, int stage0, int list0, int rot) {
     static_assert(QB % 4 == 0, "thresholds are fetched 64 queries at a time");
+    static_assert(TN <= 128, "the first-stage keys hold a 7-bit row");
+    // the key form of a young chunk's first stage (below) costs 2 * QB registers: only the 256-query form has them to
+    // spare (the 512-query form would spill), and it is the one whose chunks are short enough for the first stage to matter
+    constexpr bool KEY0 = QB <= 4;
     constexpr int STAGE_U4 = TN * 16 + TN / 4;
     constexpr int NT = TN / 16;                  // 16-row tiles per stage
     constexpr int TH_F = 3 * (QB / 4) * 64;      // fetched thresholds per wave: [3][QB/4][64 queries]
@@ -327,6 +343,7 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
 
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int chunk = (j / nQt) * 8 + xcd;
+    KT(0);
     if (chunk >= nChunks) return;
     const int qt = (j % nQt + (rot ? (xcd * nQt) >> 3 : 0)) % nQt;   // see knn2_kernel
     const int s_begin = stage0 + (int)((int64_t)nStages * chunk / nChunks);
@@ -372,38 +389,72 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
                   lds0 + (buf * STAGE_U4 + TN * 16) * 16 + wave * 256);
     };
 
+    // Bound exchange. take: fold the fetched chip-wide words into G. publish: the wave's own bounds -- in the 256-query
+    // form (KEY0: short chunks, a frame against a map) merged over the four lanes that share a query first, one atomic per
+    // word, query and wave instead of four: at a chunk's first exchange every lane has something to say, and forty
+    // workgroups per query tile say it to the same addresses (11.6 us -> 1.4 us for that exchange at 1500 x 59k).
+    auto take_bounds = [&]() {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int at = (qb >> 2) * 64 + (qb & 3) * 16 + r;
+            const float tg = ord_f(__float_as_int(thl[at]));
+            const float ta = ord_f(__float_as_int(thl[(QB / 4) * 64 + at]));
+            const float tb = ord_f(__float_as_int(thl[2 * (QB / 4) * 64 + at]));
+            // rows of lists q = 0,1 and of lists q = 2,3 are disjoint: the larger of the two groups' least bests
+            // bounds the second-best, as does the least second-best of any list
+            G[qb] = fmaxf(G[qb], -0.5f * fminf(tg, fmaxf(ta, tb)));
+        }
+    };
+    auto publish_bounds = [&]() {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int at = (qb >> 2) * 64 + (qb & 3) * 16 + r;
+            const float tg = ord_f(__float_as_int(thl[at]));
+            const float tgrp = ord_f(__float_as_int(thl[(1 + grp) * (QB / 4) * 64 + at]));
+            if (KEY0) {
+                float m2 = fminf(b2[qb], __shfl_xor(b2[qb], 16));
+                m2 = fminf(m2, __shfl_xor(m2, 32));                        // least second-best of the four lists
+                const float m1 = fminf(b1[qb], __shfl_xor(b1[qb], 16));   // least best of the group's two lists
+                if (q == 0 && m2 < tg) atomicMin(const_cast<int*>(gq) + qb * 16 + r, ord_i(m2));
+                if ((q & 1) == 0 && m1 < tgrp) atomicMin(const_cast<int*>(gq) + (1 + grp) * Qpad + qb * 16 + r, ord_i(m1));
+            } else {   // long chunks exchange rarely and have little to say: every lane for itself, no shuffles
+                if (b2[qb] < tg) atomicMin(const_cast<int*>(gq) + qb * 16 + r, ord_i(b2[qb]));
+                if (b1[qb] < tgrp) atomicMin(const_cast<int*>(gq) + (1 + grp) * Qpad + qb * 16 + r, ord_i(b1[qb]));
+            }
+        }
+    };
+    auto fetch_bounds = [&]() {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int jj = 0; jj < QB / 4; ++jj)
+                glds4_sc1(uniform_ptr(gq + a * Qpad + jj * 64), lane_now() * 4, lds_addr_of(thl) + (a * (QB / 4) + jj) * 256);
+    };
+
+    KT(1);
     if (s_begin < s_end) stage(s_begin, 0);
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        KT(4 + 2 * (s - s_begin));
         const int age = s - s_begin;
         // every stage while the chunk is young -- only workgroups of the first rounds start from loose bounds, later ones
         // inherit the chip-wide words -- then XM + 1 stages between bound exchanges
-        const bool exchange = (age < young && blockIdx.x < young_wg) || (age & XM) == 0;
+        const bool young_now = age < young && blockIdx.x < young_wg;
+        const bool exchange = young_now || (age & XM) == 0;
+        // A young chunk's second stage: the words every workgroup published after its first stage are fetched and WAITED
+        // for (about a microsecond), or this stage too would run on the wave's own bounds, i.e. through the insertion path
+        if (KEY0 && age == 1 && young_now && young > 1) {
+            fetch_bounds();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (exchange) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const int at = (qb >> 2) * 64 + (qb & 3) * 16 + r;
-                const float tg = ord_f(__float_as_int(thl[at]));
-                const float ta = ord_f(__float_as_int(thl[(QB / 4) * 64 + at]));
-                const float tb = ord_f(__float_as_int(thl[2 * (QB / 4) * 64 + at]));
-                // rows of lists q = 0,1 and of lists q = 2,3 are disjoint: the larger of the two groups' least bests
-                // bounds the second-best, as does the least second-best of any list
-                G[qb] = fmaxf(G[qb], -0.5f * fminf(tg, fmaxf(ta, tb)));
-                if (b2[qb] < tg) atomicMin(const_cast<int*>(gq) + qb * 16 + r, ord_i(b2[qb]));
-                if (b1[qb] < (grp ? tb : ta)) atomicMin(const_cast<int*>(gq) + (1 + grp) * Qpad + qb * 16 + r, ord_i(b1[qb]));
-            }
+            take_bounds();
+            publish_bounds();
         }
         if (s + 1 < s_end) stage(s + 1, buf ^ 1);
-        if (exchange) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int jj = 0; jj < QB / 4; ++jj)
-                    glds4_sc1(uniform_ptr(gq + a * Qpad + jj * 64), lane_now() * 4,
-                              lds_addr_of(thl) + (a * (QB / 4) + jj) * 256);
-        }
+        if (exchange) fetch_bounds();
         const unsigned lf = lane_now();
         const unsigned frag_off = (lf & 15) * 256u + ((((lf >> 4) ^ lf) & 15) << 4);
         const uint4* img = lds + buf * STAGE_U4;
@@ -452,8 +503,49 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
             }
         };
 
+        KT(5 + 2 * (s - s_begin));
         load_tile(0);
         f32x4 acc0 = chain(0), acc1;
+        if (KEY0 && age == 0 && young_now) {
+            // A young chunk's FIRST stage has no bound to test against: nearly every block would take the insertion path
+            // (60 vector instructions). Its results go through a branch-free top-2 of 32-bit KEYS instead -- value
+            // + 2^23 (an exact integer below 2^24) above the row's 7-bit place in the stage, so key order is (value, row)
+            // order, lowest row first on ties -- 5 instructions per result; the lists are empty before this stage, so its
+            // two best keys simply become them. A pad row's +inf converts to a key above 2^31: never taken.
+            unsigned k1[QB], k2[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) { k1[qb] = 0xffffffffu; k2[qb] = 0xffffffffu; }
+            auto epilogue_key = [&](const f32x4& a, int qb, int tile) {
+                const unsigned rowl = (unsigned)tile * 16u + 4u * (unsigned)q;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    unsigned u;   // saturating conversion: +inf -> 0xffffffff
+                    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(fmaf(-2.0f, a[reg], 8388608.0f)));
+                    const unsigned key = (u << 7) | (rowl + reg);
+                    const unsigned t = max(k1[qb], key);
+                    k1[qb] = min(k1[qb], key);
+                    k2[qb] = min(k2[qb], t);
+                }
+            };
+#pragma unroll 1
+            for (int tile = 0; tile < NT; ++tile) {
+#pragma unroll
+                for (int qb = 0; qb < QB; qb += 2) {
+                    acc1 = chain(qb + 1);
+                    if (qb == QB - 2 && tile + 1 < NT) load_tile(tile + 1);
+                    epilogue_key(acc0, qb, tile);
+                    if (qb + 2 < QB) acc0 = chain(qb + 2);
+                    else if (tile + 1 < NT) acc0 = chain(0);
+                    epilogue_key(acc1, qb + 1, tile);
+                }
+            }
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (k1[qb] < 0x80000000u) { b1[qb] = (float)(k1[qb] >> 7) - 8388608.0f; i1[qb] = s * TN + (int)(k1[qb] & 127u); }
+                if (k2[qb] < 0x80000000u) { b2[qb] = (float)(k2[qb] >> 7) - 8388608.0f; i2[qb] = s * TN + (int)(k2[qb] & 127u); }
+                G[qb] = fmaxf(G[qb], -0.5f * b2[qb]);
+            }
+        } else {
 #pragma unroll 1
         for (int tile = 0; tile < NT; ++tile) {
 #pragma unroll
@@ -466,8 +558,11 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
                 epilogue(acc1, qb + 1, tile);
             }
         }
+        }
+        if (KEY0 && age == 0 && young_now && young > 1) publish_bounds();   // read back, and waited for, at the top of the next stage
     }
 
+    KT(2);
     // The four lanes that hold a query's lists (row quarters, disjoint rows) merge them by two exchange rounds, in
     // (value, train index) order -- the values are exact integers, so equal values are true ties and the lower index
     // ranks first, as the ascending scan would have it; one partial list per chunk is written.
@@ -494,6 +589,7 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
             pi[o] = make_int2(i1[qb], i2[qb]);
         }
     }
+    KT(3);
 }
 
 __device__ inline void top2_insert(int& s1, int& j1, int& s2, int& j2, int s, int j) {
@@ -798,7 +894,9 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     // chunks of a range of stages: a multiple of 8 (one group per XCD); about two workgroups per CU slot; >= 4 stages each
     auto pick_chunks = [&](int nStages) {
         // (rounded DOWN to a multiple of 8, so that the grid stays within two rounds of slots)
-        int c = ((2 * slots + nQt - 1) / nQt / 8) * 8;
+        // -- ONE round for the 256-query form: its launches are short (a frame against a map of well under a million
+        // rows), a second, partly filled round would be a large part of them (1500 x 59k: 54 -> 44 us, 2951 x 59k: 76 -> 67)
+        int c = (((small16 ? 1 : 2) * slots + (small16 ? 0 : nQt - 1)) / nQt / 8) * 8;
         // ... and chunks of at most 16k rows (4 MB, one XCD's L2): the query tiles that share a chunk then
         // re-read it from L2 however far apart they run, and the many short workgroups balance the tail
         c = std::max(c, (int)(((int64_t)nStages * TNs + 16383) / 16384 + 7) / 8 * 8);

@@ -73,8 +73,13 @@ struct imatch_sift_state {
     // chain: on large images octave 0's layers nl+1, nl+2 and scan (main stream) run beside ALL later octaves
     // (this second stream, forked after octave 0's layer nl, joined before the refinement). The later
     // octaves are a quarter of the bytes but mostly launch latency, which the overlap hides.
+    // On a camera frame every launch is a few microseconds of latency and the chain is what costs: there the main
+    // stream runs only what the NEXT octave waits for (layers 1..nl of every octave, then the small-octave kernel) and
+    // the second stream runs each octave's layers nl+1, nl+2 and scan behind an event per octave (ev_oct).
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
+    hipEvent_t ev_oct[MAX_OCT];
+    bool have_ev_oct;
 };
 
 void imatch_sift_state_free(imatch_ctx* ctx) {
@@ -84,6 +89,8 @@ void imatch_sift_state_free(imatch_ctx* ctx) {
         (void)hipStreamSynchronize(ctx->sift->side);
         (void)hipEventDestroy(ctx->sift->ev_fork);
         (void)hipEventDestroy(ctx->sift->ev_join);
+        if (ctx->sift->have_ev_oct)
+            for (int o = 0; o < MAX_OCT; ++o) (void)hipEventDestroy(ctx->sift->ev_oct[o]);
         (void)hipStreamDestroy(ctx->sift->side);
     }
     free(ctx->sift);
@@ -1336,12 +1343,16 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         const float thr = (float)(int)floor(0.5 * P->contrast_threshold / nl * 255);
         // octaves from o_tail on go to the single-workgroup kernel
         int o_tail = n_oct;
-        for (int o = n_oct - 1; o >= 1 && (size_t)T.rows[o] * T.cols[o] <= TAIL_MAXPX; --o) o_tail = o;
+        static const size_t tail_px = getenv("IMATCH_SIFT_TAILPX") ? (size_t)atoi(getenv("IMATCH_SIFT_TAILPX")) : TAIL_MAXPX;
+        for (int o = n_oct - 1; o >= 1 && (size_t)T.rows[o] * T.cols[o] <= std::min<size_t>(tail_px, TAIL_MAXPX); --o) o_tail = o;
         // fork/join (see imatch_sift_state); the runtime-radius blur shares d_tmp, so it stays on one stream.
         // An event record + cross-stream wait costs ~20 us (tools/launch_bench.hip), so small work stays serial.
         bool use_side = all_templated && n_oct > 1 && (size_t)brows * bcols * batch >= ((size_t)1 << 22);
         if (const char* e = getenv("IMATCH_SIFT_SIDE")) use_side = use_side && atoi(e) != 0;   // experiments
-        if (use_side && !S->side) {
+        // small inputs: the chain-splitting form (see imatch_sift_state)
+        bool split = all_templated && n_oct > 1 && !use_side && o_tail >= 1 && nl == 3;
+        if (const char* e = getenv("IMATCH_SIFT_SPLIT")) split = split && atoi(e) != 0;        // experiments
+        if ((use_side || split) && !S->side) {
             // highest priority: the later octaves' small launches must get CU slots while octave 0's big kernels
             // are resident, or they queue behind them and the overlap is lost
             int prio_least = 0, prio_greatest = 0;
@@ -1350,9 +1361,44 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming));
         }
+        if (split && !S->have_ev_oct) {
+            for (int o = 0; o < MAX_OCT; ++o) HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_oct[o], hipEventDisableTiming));
+            S->have_ev_oct = true;
+        }
         hipStream_t st2 = use_side ? S->side : ctx->stream;
+        auto scan_octave = [&](int o, hipStream_t st) {
+            const int rows = T.rows[o], cols = T.cols[o];
+            if (rows <= 2 * SIFT_IMG_BORDER || cols <= 2 * SIFT_IMG_BORDER) return;
+            const int iw = cols - 2 * SIFT_IMG_BORDER, ih = rows - 2 * SIFT_IMG_BORDER;
+            if (nl == 3) {
+                const size_t px = (size_t)iw * ih * batch;
+                const int rpw = px >= ((size_t)1 << 26) ? 64 : px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
+                hipLaunchKernelGGL(detect_stream_kernel, dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * rpw - 1) / (4 * rpw), batch),
+                                   dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs);
+            } else {
+                hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H, batch), dim3(256),
+                                   0, st, T, o, thr, d_cand, cap, d_cnt, zs);
+            }
+        };
         bool have_l0 = true;   // layer 0 of octave o was written by the previous octave's layer-nl blur
-        for (int o = 0; o < o_tail; ++o) {
+        for (int o = 0; o < o_tail && split; ++o) {
+            const int rows = T.rows[o], cols = T.cols[o];
+            for (int i = 1; i <= nl; ++i) {
+                float* dec = (i == nl && o + 1 < o_tail) ? T.gauss[o + 1][0] : nullptr;
+                rc = gaussian_blur(ctx, ctx->stream, T.gauss[o][i - 1], nullptr, 0, 0, T.gauss[o][i], dec, d_tmp, rows, cols, sig[i],
+                                   batch, zs, nullptr);
+                if (rc) return rc;
+            }
+            HIP_TRY(ctx, hipEventRecord(S->ev_oct[o], ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(S->side, S->ev_oct[o], 0));
+            for (int i = nl + 1; i < nl + 3; ++i) {
+                rc = gaussian_blur(ctx, S->side, T.gauss[o][i - 1], nullptr, 0, 0, T.gauss[o][i], nullptr, d_tmp, rows, cols, sig[i],
+                                   batch, zs, nullptr);
+                if (rc) return rc;
+            }
+            scan_octave(o, S->side);
+        }
+        for (int o = 0; o < o_tail && !split; ++o) {
             const int rows = T.rows[o], cols = T.cols[o];
             hipStream_t st = o == 0 ? ctx->stream : st2;
             if (o > 0 && !have_l0)
@@ -1373,19 +1419,10 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                     }
                 }
             }
-            if (rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER) {
-                const int iw = cols - 2 * SIFT_IMG_BORDER, ih = rows - 2 * SIFT_IMG_BORDER;
-                if (nl == 3) {
-                    const size_t px = (size_t)iw * ih * batch;
-                    const int rpw = px >= ((size_t)1 << 26) ? 64 : px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
-                    hipLaunchKernelGGL(detect_stream_kernel,
-                                       dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * rpw - 1) / (4 * rpw), batch), dim3(256), 0, st,
-                                       T, o, rpw, thr, d_cand, cap, d_cnt, zs);
-                } else {
-                    hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H, batch),
-                                       dim3(256), 0, st, T, o, thr, d_cand, cap, d_cnt, zs);
-                }
-            }
+            scan_octave(o, st);
+        }
+        if (split) {   // the small octaves follow layer nl of octave o_tail - 1 on the main stream; the scans join below
+            st2 = ctx->stream;
         }
         hipStream_t st_tail = st2;   // o_tail >= 1: the tail needs layer nl of octave o_tail - 1, which precedes it on st2 (or the fork)
         bool tail_fast = o_tail < n_oct && nl == 3 &&
@@ -1426,8 +1463,8 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                                thr, d_cand, cap, d_cnt, zs);
         }
         HIP_TRY(ctx, hipGetLastError());
-        if (use_side) {
-            HIP_TRY(ctx, hipEventRecord(S->ev_join, st2));
+        if (use_side || split) {
+            HIP_TRY(ctx, hipEventRecord(S->ev_join, S->side));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, S->ev_join, 0));
         }
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
