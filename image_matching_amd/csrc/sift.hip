@@ -571,18 +571,44 @@ __device__ __forceinline__ void tf_col_pass(float* __restrict__ A, const float* 
     }
 }
 
-// margin <- copies of the interior through reflect-101
+// margin <- copies of the interior through reflect-101, M cells deep (the next layer's radius). Two index spaces with
+// cheap arithmetic -- the side margins of the interior rows, then the bands above and below with their corners -- where
+// one loop over the whole extended rectangle spent 3 us per layer of a 60 x 80 octave on divisions.
+template <int M>
 __device__ __forceinline__ void tf_mirror(float* __restrict__ A, int rows, int cols, int P) {
-    const int ew = cols + 2 * TF_M, n = (rows + 2 * TF_M) * ew;
-    for (int p = threadIdx.x; p < n; p += 1024) {
-        const int yy = p / ew, xx = p - yy * ew;
-        const int y = yy - TF_M, x = xx - TF_M;
-        if ((unsigned)y >= (unsigned)rows || (unsigned)x >= (unsigned)cols)
-            A[yy * P + TF_XO + x] = A[(reflect101(y, rows) + TF_M) * P + TF_XO + reflect101(x, cols)];
+    for (int p = threadIdx.x; p < rows * (2 * M); p += 1024) {
+        const int y = p / (2 * M), k = p - y * (2 * M);          // constant divisor
+        const int x = k < M ? -1 - k : cols + (k - M);
+        float* row = A + (y + TF_M) * P + TF_XO;
+        row[x] = row[reflect101(x, cols)];
+    }
+    const int ew = cols + 2 * M;                                 // mostly <= 128: one trip
+    for (int xx = threadIdx.x & 127; xx < ew; xx += 128) {
+        const int x = xx - M, sx = reflect101(x, cols);
+        for (int b = threadIdx.x >> 7; b < 2 * M; b += 8) {
+            const int y = b < M ? -1 - b : rows + (b - M);
+            A[(y + TF_M) * P + TF_XO + x] = A[(reflect101(y, rows) + TF_M) * P + TF_XO + sx];
+        }
     }
 }
 
-template <int R1, int R2, int R3, int R4, int R5>
+#ifdef TAIL_TRACE   // development only (tools/dbg/tail_trace.py)
+__device__ long long tail_trace[256];
+__device__ int tail_trace_n;
+#define TT() do { if (threadIdx.x == 0 && blockIdx.z == 0 && tt_n < 256) tail_trace[tt_n++] = (long long)wall_clock64(); } while (0)
+extern "C" int imatch_dbg_tail_trace(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tail_trace), sizeof(long long) * 256);
+}
+#else
+#define TT() do {} while (0)
+#endif
+// SPLIT: one workgroup per octave (blockIdx.x), for single frames, where this kernel is a third of the scale-space chain:
+// octave o + 1 needs only layer nl of octave o, so its workgroup starts as soon as that layer is in the global pyramid
+// (a flag per octave in the image's counter block, release / acquire at agent scope) while octave o's workgroup goes on
+// with its last two layers and scans. A consumer has a higher workgroup index than its producer and workgroups are
+// dispatched in index order, so a waiting workgroup never keeps its producer off the chip. A batch keeps the one-workgroup
+// walk: there the waiting workgroups would hold CUs that other images' kernels can use.
+template <int R1, int R2, int R3, int R4, int R5, bool SPLIT>
 __global__ void __launch_bounds__(1024)
 pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* __restrict__ cand, int cap,
                          int* __restrict__ count, size_t zs) {
@@ -598,23 +624,48 @@ pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* _
     int* const wcnt = (int*)((uint2*)(nx + TAIL_MAXPX / 4) + 16 * TAIL_STAGE);
     const int tid = threadIdx.x;
     int n_staged = 0;
-    for (int o = o_start; o < T.n_oct; ++o) {
+    int tt_n = 0; (void)tt_n;
+    TT();
+    int* const ready = count + 16;        // [octave]: layer nl of that octave is in the global pyramid (SPLIT)
+    const int o_first = SPLIT ? o_start + (int)blockIdx.x : o_start, o_last = SPLIT ? o_first + 1 : T.n_oct;
+    for (int o = o_first; o < o_last; ++o) {
         const int rows = T.rows[o], cols = T.cols[o], n = rows * cols, P = tf_pitch(cols);
+        if (SPLIT && o > o_start) {
+            if (tid == 0)
+                while (__hip_atomic_load(ready + (o - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         {
             const float* up = TG(o - 1, T.nl);
             const int ucols = T.cols[o - 1];
             float* g0 = TG(o, 0);
-            for (int p = tid; p < n; p += 1024) {
-                const int y = p / cols, x = p - y * cols;
-                const float v = o == o_start ? up[(size_t)(2 * y) * ucols + 2 * x] : nx[p];
-                A[(y + TF_M) * P + TF_XO + x] = v;
-                g0[p] = v;
+            const bool from_global = SPLIT || o == o_start;
+            float v[(TAIL_MAXPX + 1023) / 1024];   // all loads in flight before the first store
+#pragma unroll
+            for (int k = 0; k < (TAIL_MAXPX + 1023) / 1024; ++k) {
+                const int p = tid + 1024 * k;
+                if (p < n) {
+                    const int y = p / cols, x = p - y * cols;
+                    v[k] = from_global ? up[(size_t)(2 * y) * ucols + 2 * x] : nx[p];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < (TAIL_MAXPX + 1023) / 1024; ++k) {
+                const int p = tid + 1024 * k;
+                if (p < n) {
+                    const int y = p / cols, x = p - y * cols;
+                    A[(y + TF_M) * P + TF_XO + x] = v[k];
+                    g0[p] = v[k];
+                }
             }
         }
         __syncthreads();
-        tf_mirror(A, rows, cols, P);
+        TT();
+        tf_mirror<R1>(A, rows, cols, P);
         __syncthreads();
-        float* const nxo = o + 1 < T.n_oct ? nx : nullptr;
+        TT();
+        float* const nxo = (!SPLIT && o + 1 < T.n_oct) ? nx : nullptr;
         const bool scan_ok = rows > 2 * SIFT_IMG_BORDER && cols > 2 * SIFT_IMG_BORDER;
         auto scan = [&](int j) {  // DoG layers j-1, j, j+1 sit in the ring
             if (!scan_ok) return;
@@ -651,20 +702,37 @@ pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* _
                                                 count);
             }
         };
-#define TF_LAYER(I, R, NX)                                                                                         \
+#define TF_LAYER(I, R, RNEXT, NX)                                                                                  \
         tf_row_pass<R>(A, tm, gk.k[I - 1], rows, cols, P);                                                         \
         __syncthreads(); /* also: the scan before this is done with the ring slot rewritten next */              \
+        TT();                                                                                                      \
         tf_col_pass<R>(A, tm, gk.k[I - 1], rows, cols, P, dg + ((I - 1) % 3) * TAIL_MAXPX, TG(o, I), NX);     \
         __syncthreads();                                                                                           \
-        if (I < 5) { tf_mirror(A, rows, cols, P); __syncthreads(); }
-        TF_LAYER(1, R1, nullptr)
-        TF_LAYER(2, R2, nullptr)
-        TF_LAYER(3, R3, nxo)
+        TT();                                                                                                      \
+        if (I < 5) { tf_mirror<RNEXT>(A, rows, cols, P); __syncthreads(); TT(); }
+        TF_LAYER(1, R1, R2, nullptr)
+        TF_LAYER(2, R2, R3, nullptr)
+        if (SPLIT && o + 1 < T.n_oct) {
+            // layer nl for the next octave's workgroup: own stores out, everybody's (barrier), then the flag
+            tf_row_pass<R3>(A, tm, gk.k[2], rows, cols, P);
+            __syncthreads();
+            tf_col_pass<R3>(A, tm, gk.k[2], rows, cols, P, dg + 2 * TAIL_MAXPX, TG(o, 3), nullptr);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(ready + o, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tf_mirror<R4>(A, rows, cols, P);
+            __syncthreads();
+        } else {
+            TF_LAYER(3, R3, R4, nxo)
+        }
         scan(1);
-        TF_LAYER(4, R4, nullptr)
+        TT();
+        TF_LAYER(4, R4, R5, nullptr)
         scan(2);
-        TF_LAYER(5, R5, nullptr)
+        TT();
+        TF_LAYER(5, R5, R5, nullptr)
         scan(3);
+        TT();
 #undef TF_LAYER
         __syncthreads();  // nx, A and the ring are rewritten by the next octave
     }
@@ -1069,6 +1137,154 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
     }
 }
 
+// ---- KeyPoint12_LessThan sort + removeDuplicatedSorted + first-octave rescale on the device ------------------------------
+// A camera frame has a few thousand keypoint records: fetching them, sorting them on the host and sending them back held
+// the GPU idle for ~115 us of a 0.7 ms frame. Two short kernels do it where the records lie.
+//   kp_rank_kernel    a record's place in the sorted list is the number of records that come before it: every workgroup
+//                     holds ALL keys (order-preserving bits of x and y, 8 B each) in LDS, sixteen lanes share a record
+//                     and count a sixteenth of the keys each (a broadcast LDS read, a 64-bit compare and an add per
+//                     key); records of equal (x, y) -- the several orientations of one point -- are ordered by the full
+//                     comparator (size desc, angle asc, response desc, octave desc), read from the records themselves.
+//   kp_dedupe_kernel  one workgroup per image: duplicates (equal x, y, size, angle) are neighbours now and are dropped,
+//                     the rest rescaled to the input image's frame and written back to back.
+// Above the launch's limit (the previous extraction's count plus a margin, at most SORT_CAP) the kernels report -1 and
+// the host's radix sort runs on the raw records.
+#define SORT_CAP 8192
+
+__device__ __forceinline__ unsigned ord_bits(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// a before b, keys equal
+__device__ __forceinline__ bool kp_tie_before(const KpRec* __restrict__ rec, int ia, int ib) {
+    const KpRec a = rec[ia], b = rec[ib];
+    if (a.size != b.size) return a.size > b.size;
+    if (a.angle != b.angle) return a.angle < b.angle;
+    if (a.response != b.response) return a.response > b.response;
+    if (a.octave != b.octave) return a.octave > b.octave;
+    return ia < ib;
+}
+
+template <int TPR>   // lanes per record: 16 for one frame (many short workgroups), 4 for a batch (fewer copies of the keys)
+__global__ void __launch_bounds__(256)
+kp_rank_kernel(const KpRec* __restrict__ rec, const int* __restrict__ n_dev, int limit, int* __restrict__ order, size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    rec = ZP(rec); n_dev = ZP(n_dev); order = ZP(order);
+    extern __shared__ unsigned long long rank_keys[];
+    const int n = *n_dev;                  // limit = the keys the launch has LDS for (<= SORT_CAP)
+    constexpr int RPW = 256 / TPR;         // records per workgroup and round
+    if (n > limit || (int)blockIdx.x * RPW >= n) return;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 16) {   // sixteen loads in flight per lane: the fill is all latency
+        float2 xy[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = min(i0 + 256 * u, n - 1);
+            xy[u] = *(const float2*)&rec[i].x;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < n) rank_keys[i] = ((unsigned long long)ord_bits(xy[u].x) << 32) | ord_bits(xy[u].y);
+        }
+    }
+    __syncthreads();
+    const int part = threadIdx.x % TPR;
+    for (int i0 = blockIdx.x * RPW; i0 < n; i0 += gridDim.x * RPW) {   // (whole waves take the shuffles below)
+        const int i = min(i0 + (int)threadIdx.x / TPR, n - 1);
+        const unsigned long long mine = rank_keys[i];
+        int before = 0;
+        int j = part;
+        for (; j + 7 * TPR < n; j += 8 * TPR) {   // eight LDS reads in flight: one wave per SIMD has nothing else to hide them
+            unsigned long long k[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k[u] = rank_keys[j + u * TPR];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k[u] < mine) ++before;
+                else if (k[u] == mine && j + u * TPR != i && kp_tie_before(rec, j + u * TPR, i)) ++before;
+            }
+        }
+        for (; j < n; j += TPR) {
+            const unsigned long long k = rank_keys[j];
+            if (k < mine) ++before;
+            else if (k == mine && j != i && kp_tie_before(rec, j, i)) ++before;
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) before += __shfl_xor(before, o);
+        if (part == 0 && i0 + (int)threadIdx.x / TPR < n) order[before] = i;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+kp_dedupe_kernel(const KpRec* __restrict__ rec, const int* __restrict__ n_dev, int limit, const int* __restrict__ order,
+                 KpRec* __restrict__ out, int* __restrict__ k_out, int first_octave, size_t zs) {
+    const size_t zo = (size_t)blockIdx.z * zs;
+    rec = ZP(rec); n_dev = ZP(n_dev); order = ZP(order); out = ZP(out); k_out = ZP(k_out);
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x;
+    const int n = *n_dev;
+    if (n > limit) {                       // the rank kernel did not run either
+        if (tid == 0) *k_out = -1;
+        return;
+    }
+    // keep flags: place i against place i - 1, strided over the threads so that the loads of the E rounds overlap
+    constexpr int E = SORT_CAP / 1024;
+    __shared__ unsigned char keep_s[SORT_CAP];
+    __shared__ unsigned short off_s[SORT_CAP];
+    KpRec mine_rec[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid + 1024 * e;
+        bool kp = false;
+        if (i < n) {
+            const KpRec c = rec[order[i]];
+            mine_rec[e] = c;
+            kp = true;
+            if (i > 0) {
+                const KpRec a = rec[order[i - 1]];
+                kp = a.x != c.x || a.y != c.y || a.size != c.size || a.angle != c.angle;
+            }
+        }
+        keep_s[i] = kp;
+    }
+    __syncthreads();
+    // exclusive scan over consecutive runs of E places per thread
+    const int base = tid * E;
+    int mine = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) mine += keep_s[base + e];
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = incl - mine;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        off_s[base + e] = (unsigned short)off;
+        off += keep_s[base + e];
+    }
+    if (tid == 1023) *k_out = off;
+    __syncthreads();
+    const float scale = 1.f / (float)(1 << -first_octave);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < n && keep_s[i]) {
+            KpRec k = mine_rec[e];
+            k.octave = (k.octave & ~255) | ((k.octave + first_octave) & 255);
+            k.x *= scale; k.y *= scale; k.size *= scale;
+            out[off_s[i]] = k;
+        }
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 // getGaussianKernel(ksize, sigma, CV_32F), bit-exact form (see oracle/sift_oracle.c oracle_gauss_kernel)
 static int gauss_kernel(double sigma, float* k, int maxn) {
@@ -1439,12 +1655,20 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if (tail_fast) {
             static bool attr_set[64] = {false};
             if (!attr_set[ctx->device & 63]) {
-                HIP_TRY(ctx, hipFuncSetAttribute((const void*)pyramid_tail_fast_kernel<5, 6, 8, 10, 13>,
+                HIP_TRY(ctx, hipFuncSetAttribute((const void*)pyramid_tail_fast_kernel<5, 6, 8, 10, 13, false>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS_BYTES));
+                HIP_TRY(ctx, hipFuncSetAttribute((const void*)pyramid_tail_fast_kernel<5, 6, 8, 10, 13, true>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS_BYTES));
                 attr_set[ctx->device & 63] = true;
             }
-            hipLaunchKernelGGL((pyramid_tail_fast_kernel<5, 6, 8, 10, 13>), dim3(1, 1, batch), dim3(1024), TF_LDS_BYTES,
-                               st_tail, T, o_tail, tfk, thr, d_cand, cap, d_cnt, zs);
+            static const int tail_split_env = getenv("IMATCH_SIFT_TAILSPLIT") ? atoi(getenv("IMATCH_SIFT_TAILSPLIT")) : 1;
+            const int n_tail = n_oct - o_tail;
+            if (tail_split_env && n_tail > 1 && n_tail <= 16 && batch * n_tail <= 32)
+                hipLaunchKernelGGL((pyramid_tail_fast_kernel<5, 6, 8, 10, 13, true>), dim3(n_tail, 1, batch), dim3(1024),
+                                   TF_LDS_BYTES, st_tail, T, o_tail, tfk, thr, d_cand, cap, d_cnt, zs);
+            else
+                hipLaunchKernelGGL((pyramid_tail_fast_kernel<5, 6, 8, 10, 13, false>), dim3(1, 1, batch), dim3(1024),
+                                   TF_LDS_BYTES, st_tail, T, o_tail, tfk, thr, d_cand, cap, d_cnt, zs);
         } else if (o_tail < n_oct) {
             TailK tk;
             memset(&tk, 0, sizeof(tk));
@@ -1476,16 +1700,43 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         hipLaunchKernelGGL(orient_kernel, dim3(std::min(std::max((ref_hint + 3) / 4, 64), 4096), 1, batch), dim3(256), 0,
                            ctx->stream, T, (const RefinedKp*)d_ref, (const int*)(d_cnt + 1), cap, d_kp, 2 * cap, d_cnt + 2, zs);
         HIP_TRY(ctx, hipGetLastError());
+        // frames: sorted, deduplicated and rescaled where they lie (sort_dedupe_kernel); maps keep the host's radix sort
+        KpRec* d_sorted = (KpRec*)d_ref;   // the refined list is no longer needed once the orientations are out
+        static const int dev_sort_env = getenv("IMATCH_SIFT_DEVSORT") ? atoi(getenv("IMATCH_SIFT_DEVSORT")) : 1;
+        const int n_sort = std::min(SORT_CAP, S->kp_hint > 0 ? S->kp_hint : 4096);   // records the device sort is launched for
+        bool dev_sort = dev_sort_env && (size_t)SORT_CAP * sizeof(KpRec) <= (size_t)cap * sizeof(RefinedKp) &&
+                        (S->kp_hint > 0 ? S->kp_hint <= SORT_CAP + SORT_CAP / 4 + 1024 : (size_t)h * w <= ((size_t)1 << 21));
+        if (dev_sort) {
+            static bool attr_set[64] = {false};
+            if (!attr_set[ctx->device & 63]) {
+                HIP_TRY(ctx, hipFuncSetAttribute((const void*)kp_rank_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 SORT_CAP * 8));
+                HIP_TRY(ctx, hipFuncSetAttribute((const void*)kp_rank_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 SORT_CAP * 8));
+                attr_set[ctx->device & 63] = true;
+            }
+            int* d_order = (int*)d_cand;       // the candidates are spent too
+            if (batch < 8)
+                hipLaunchKernelGGL(kp_rank_kernel<16>, dim3((n_sort + 15) / 16, 1, batch), dim3(256), (size_t)n_sort * 8,
+                                   ctx->stream, (const KpRec*)d_kp, (const int*)(d_cnt + 2), n_sort, d_order, zs);
+            else
+                hipLaunchKernelGGL(kp_rank_kernel<4>, dim3((n_sort + 63) / 64, 1, batch), dim3(256), (size_t)n_sort * 8,
+                                   ctx->stream, (const KpRec*)d_kp, (const int*)(d_cnt + 2), n_sort, d_order, zs);
+            hipLaunchKernelGGL(kp_dedupe_kernel, dim3(1, 1, batch), dim3(1024), 0, ctx->stream, (const KpRec*)d_kp,
+                               (const int*)(d_cnt + 2), n_sort, (const int*)d_order, d_sorted, d_cnt + 3, first_octave, zs);
+            HIP_TRY(ctx, hipGetLastError());
+        }
         // ---- the extraction's one synchronisation: the counters and (a guess of) the records of every image
         int kp_hint = std::min(2 * cap, S->kp_hint > 0 ? S->kp_hint : 8192);
+        if (dev_sort) kp_hint = std::min(kp_hint, SORT_CAP);
         const size_t cnt_bytes = al((size_t)batch * 16);
         rc = imatch_hs_reserve(ctx, cnt_bytes + (size_t)batch * kp_hint * sizeof(KpRec));
         if (rc) return rc;
         int* h_cnt = (int*)ctx->hs;                              // [batch][4]
         KpRec* h_kp = (KpRec*)((char*)ctx->hs + cnt_bytes);      // [batch][kp_hint]
         HIP_TRY(ctx, hipMemcpy2DAsync(h_cnt, 16, d_cnt, zs, 16, (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), d_kp, zs, (size_t)kp_hint * sizeof(KpRec),
-                                      (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), dev_sort ? d_sorted : d_kp, zs,
+                                      (size_t)kp_hint * sizeof(KpRec), (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
         const bool timing = getenv("IMATCH_TIMING") != nullptr;
         const double t_a = now_ms();
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1508,13 +1759,27 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         S->kp_hint = max_kp + max_kp / 4 + 1024;
         std::vector<int> n_kp((size_t)batch);
         for (int b = 0; b < batch; ++b) n_kp[b] = h_cnt[4 * b + 2];
-        if (max_kp > kp_hint) {  // the guess was short: fetch everything again at the right width
-            kp_hint = max_kp;
+        bool refetch = false;
+        if (dev_sort && max_kp > n_sort) {   // more records than the device sort was launched for: the host sorts the raw ones
+            dev_sort = false;
+            refetch = true;
+        }
+        std::vector<int> K_dev((size_t)batch, 0);
+        int max_fetch = max_kp;
+        if (dev_sort) {
+            max_fetch = 0;
+            for (int b = 0; b < batch; ++b) {
+                K_dev[b] = h_cnt[4 * b + 3];
+                max_fetch = std::max(max_fetch, K_dev[b]);
+            }
+        }
+        if (refetch || max_fetch > kp_hint) {  // the guess was short: fetch everything again at the right width
+            kp_hint = std::max(kp_hint, max_fetch);
             rc = imatch_hs_reserve(ctx, cnt_bytes + (size_t)batch * kp_hint * sizeof(KpRec));  // may move hs
             if (rc) return rc;
             h_kp = (KpRec*)((char*)ctx->hs + cnt_bytes);
-            HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), d_kp, zs, (size_t)kp_hint * sizeof(KpRec),
-                                          (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), dev_sort ? d_sorted : d_kp, zs,
+                                          (size_t)kp_hint * sizeof(KpRec), (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
         // ---- removeDuplicatedSorted + first-octave rescale on the host (K records of 24 bytes per image);
@@ -1543,7 +1808,9 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             memcpy(rec, kps.data(), (size_t)K * sizeof(KpRec));
             K_of[b] = K;
         };
-        if (batch >= 4) {  // the images' lists are independent: sort them on the context's host workers
+        if (dev_sort) {
+            for (int b = 0; b < batch; ++b) K_of[b] = K_dev[b];
+        } else if (batch >= 4) {  // the images' lists are independent: sort them on the context's host workers
             imatch_parallel_for(ctx, batch, [&](int b) {
                 std::vector<KpRec> kps;
                 finish_image(b, kps);
@@ -1588,7 +1855,6 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             HIP_TRY(ctx, hipMemcpyAsync(f->image, d_clahe, (size_t)h * w, hipMemcpyDeviceToDevice, ctx->stream));
         }
         // sorted records and u8 descriptors reuse the candidate / refined lists (no longer needed)
-        KpRec* d_sorted = (KpRec*)d_ref;
         uint8_t* d_desc = (uint8_t*)d_kp;  // cap*2*24 bytes >= K*128 needs K <= cap*0.375: checked below
         if ((size_t)max_k * 128 > (size_t)cap * 2 * sizeof(KpRec) || (size_t)max_k * sizeof(KpRec) > (size_t)cap * sizeof(RefinedKp)) {
             imatch_features_free(f);
@@ -1598,10 +1864,12 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if (Ktot > 0) {
             // this copy is still reading the pinned rows when the call returns: the next writer of ctx->hs waits for it
             // (imatch_hs_reserve)
-            HIP_TRY(ctx, hipMemcpy2DAsync(d_sorted, zs, h_kp, (size_t)kp_hint * sizeof(KpRec), (size_t)max_k * sizeof(KpRec),
-                                          (size_t)batch, hipMemcpyHostToDevice, ctx->stream));
-            rc = imatch_hs_mark_busy(ctx);
-            if (rc) { imatch_features_free(f); return rc; }
+            if (!dev_sort) {
+                HIP_TRY(ctx, hipMemcpy2DAsync(d_sorted, zs, h_kp, (size_t)kp_hint * sizeof(KpRec), (size_t)max_k * sizeof(KpRec),
+                                              (size_t)batch, hipMemcpyHostToDevice, ctx->stream));
+                rc = imatch_hs_mark_busy(ctx);
+                if (rc) { imatch_features_free(f); return rc; }
+            }
             // Four waves per keypoint everywhere, the 236 k keypoints of an 8192^2 map included: with one wave per keypoint
             // (four keypoints of different window sizes per workgroup) the map's launch took 3.15 ms against 2.4 ms, a
             // 64-frame batch 2.2 ms against 1.7 ms -- the waves of a workgroup finish together when they share a keypoint.
