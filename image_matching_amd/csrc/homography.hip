@@ -99,7 +99,7 @@ homography_score_kernel(const double* __restrict__ pts_all, const float* __restr
     const float* fpts = fpts_all + 4 * (size_t)hs.seg.off[b];
     const uint64_t seed = hs.seeds[b];
     const float inv_tau2 = hs.inv_tau2[b];
-    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= HOMO_HYPOTHESES) return;
     double H[9];
     if (!hypothesis(pts, n, seed, h, H)) return;
@@ -236,7 +236,9 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
     unsigned long long* d_best = (unsigned long long*)(dev + dbytes + fbytes);
     HIP_TRY(ctx, hipMemcpyAsync(dev, ctx->hs, dbytes + fbytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_best, 0, kbytes, ctx->stream));
-    hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / 256, nseg), dim3(256), 0, ctx->stream,
+    // one problem: single-wave workgroups, or its 4096 hypotheses sit on 16 of the 256 CUs
+    const int wg = nseg >= 8 ? 256 : 64;
+    hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / wg, nseg), dim3(wg), 0, ctx->stream,
                        (const double*)dev, (const float*)(dev + dbytes), hs, d_best);
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long* h_key = (unsigned long long*)((char*)ctx->hs + dbytes + fbytes);  // pinned: no staging copy

@@ -610,11 +610,21 @@ knn2_finish_kernel(const float2* __restrict__ pb, const int2* __restrict__ pi, i
     const int64_t q = (int64_t)blockIdx.x * 16 + ql;
     int s1 = INT_MAX, s2 = INT_MAX, j1 = INT_MAX, j2 = INT_MAX;
     if (q < nq) {
-        for (int l = slice; l < nLists; l += 16) {
-            const float2 b = pb[(int64_t)l * Qpad + q];
-            const int2 i = pi[(int64_t)l * Qpad + q];
-            if (i.x >= 0 && i.x < nt) top2_insert(s1, j1, s2, j2, (int)b.x, i.x);
-            if (i.y >= 0 && i.y < nt) top2_insert(s1, j1, s2, j2, (int)b.y, i.y);
+        for (int l0 = slice; l0 < nLists; l0 += 64) {   // four lists' loads in flight (a frame's launch has 40 to 112 lists)
+            float2 b[4];
+            int2 i[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int l = min(l0 + 16 * u, nLists - 1);
+                b[u] = pb[(int64_t)l * Qpad + q];
+                i[u] = pi[(int64_t)l * Qpad + q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (l0 + 16 * u >= nLists) break;
+                if (i[u].x >= 0 && i[u].x < nt) top2_insert(s1, j1, s2, j2, (int)b[u].x, i[u].x);
+                if (i[u].y >= 0 && i[u].y < nt) top2_insert(s1, j1, s2, j2, (int)b[u].y, i[u].y);
+            }
         }
     }
     part[slice][ql] = make_int4(s1, j1, s2, j2);

@@ -124,6 +124,10 @@ int imatch_clahe_dev(imatch_ctx* ctx, const uint8_t* src_dev, int h, int w, int 
     else HIP_TRY(ctx, hipMemset2DAsync(hist, zs, 0, (size_t)tiles * 1024, (size_t)batch, ctx->stream));
     int slices = (th + 63) / 64;
     if (slices > 64) slices = 64;
+    // a camera frame has 64 tiles of 60 rows: one workgroup per tile walks them with one dependent byte load after the
+    // other (12 us of a 0.7 ms frame); bands of four rows make it a thousand short workgroups instead
+    if ((long long)tiles * slices * batch < 1024) slices = std::min((th + 3) / 4, (int)((1024 + (long long)tiles * batch - 1) / ((long long)tiles * batch)));
+    if (slices < 1) slices = 1;
     hipLaunchKernelGGL(clahe_hist_kernel, dim3(tiles, slices, batch), dim3(256), 0, ctx->stream, src_dev, h, w, stride, tw,
                        th, tiles_x, hist, src_zs, zs);
     hipLaunchKernelGGL(clahe_lut_kernel, dim3(tiles, 1, batch), dim3(256), 0, ctx->stream, hist, clip, (float)255 / total, lut,

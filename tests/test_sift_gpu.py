@@ -170,3 +170,34 @@ def test_calls_right_after_an_extraction_do_not_disturb_its_descriptors(ctx):
         kp, desc = f.download()
         assert np.array_equal(kp, ref_kp) and np.array_equal(desc, ref_desc), follow
         f.free()
+
+
+def test_device_sort_and_its_host_fallback_agree_with_the_oracle():
+    """Frames are sorted, deduplicated and rescaled on the device (kp_rank_kernel / kp_dedupe_kernel), launched for the
+    previous extraction's keypoint count plus a margin; an image with more records than that goes through the host's
+    radix sort in the same call. Both must give the oracle's list, record for record: a fresh context sees a small image
+    first (few keypoints: a small launch), then a 1024^2 image (several thousand: host fallback), then the same image
+    again (the launch is large enough now: device sort)."""
+    c = im.Context(0)
+    m = synth.synth_map(1024, seed=21)
+    small = np.ascontiguousarray(m[:96, :128])
+    p = im.SiftParams(clahe=True)
+    f0 = c.sift_extract(small, p)
+    want0 = oracle.sift(oracle.clahe(small))
+    kp0 = f0.download(descriptors=False)[0]
+    assert len(kp0) == len(want0.kp) < 400 and np.array_equal(kp0[:, :2], want0.kp[:, :2])
+    want = oracle.sift(oracle.clahe(m))
+    assert 2000 < len(want.kp) <= 8192, len(want.kp)
+    runs = []
+    for _ in range(2):
+        f = c.sift_extract(m, p)
+        kp, desc = f.download()
+        runs.append((kp, desc))
+        f.free()
+    for kp, desc in runs:
+        assert len(kp) == len(want.kp)
+        assert np.array_equal(kp[:, :2], want.kp[:, :2]) and np.array_equal(kp[:, 4:], want.kp[:, 4:])
+        assert np.abs(kp[:, 2] - want.kp[:, 2]).max() <= 1e-4
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    f0.free()
+    c.close() if hasattr(c, "close") else None
