@@ -322,7 +322,9 @@ extern "C" int imatch_dbg_knn_trace(long long* out) {
 #define KT(slot) do {} while (0)
 #endif
 
-template <int QB, int TN, int XM>   // QB blocks of 16 queries per wave (8: 128 queries, 512 per workgroup as above)
+// SHORT: the 512-query form for a few query tiles against chunks of a few dozen stages (a frame against a large map):
+// the 256-query form's first exchange (merged publishing, waited for) without its key registers.
+template <int QB, int TN, int XM, bool SHORT = false>   // QB blocks of 16 queries per wave (8: 128 queries, 512 per workgroup as above)
 __global__ void __launch_bounds__(256, 2)
 knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ thneg,
               int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi,
@@ -332,6 +334,7 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
     // the key form of a young chunk's first stage (below) costs 2 * QB registers: only the 256-query form has them to
     // spare (the 512-query form would spill), and it is the one whose chunks are short enough for the first stage to matter
     constexpr bool KEY0 = QB <= 4;
+    constexpr bool MERGED = KEY0 || SHORT;   // lane-merged publishing; the second stage waits for the first exchange
     constexpr int STAGE_U4 = TN * 16 + TN / 4;
     constexpr int NT = TN / 16;                  // 16-row tiles per stage
     constexpr int TH_F = 3 * (QB / 4) * 64;      // fetched thresholds per wave: [3][QB/4][64 queries]
@@ -411,7 +414,7 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
             const int at = (qb >> 2) * 64 + (qb & 3) * 16 + r;
             const float tg = ord_f(__float_as_int(thl[at]));
             const float tgrp = ord_f(__float_as_int(thl[(1 + grp) * (QB / 4) * 64 + at]));
-            if (KEY0) {
+            if (MERGED) {
                 float m2 = fminf(b2[qb], __shfl_xor(b2[qb], 16));
                 m2 = fminf(m2, __shfl_xor(m2, 32));                        // least second-best of the four lists
                 const float m1 = fminf(b1[qb], __shfl_xor(b1[qb], 16));   // least best of the group's two lists
@@ -445,7 +448,7 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
         const bool exchange = young_now || (age & XM) == 0;
         // A young chunk's second stage: the words every workgroup published after its first stage are fetched and WAITED
         // for (about a microsecond), or this stage too would run on the wave's own bounds, i.e. through the insertion path
-        if (KEY0 && age == 1 && young_now && young > 1) {
+        if (MERGED && age == 1 && young_now && young > 1) {
             fetch_bounds();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -559,7 +562,7 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
             }
         }
         }
-        if (KEY0 && age == 0 && young_now && young > 1) publish_bounds();   // read back, and waited for, at the top of the next stage
+        if (MERGED && age == 0 && young_now && young > 1) publish_bounds();   // read back, and waited for, at the top of the next stage
     }
 
     KT(2);
@@ -894,7 +897,15 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     // lists weigh half as much (0.284 -> 0.242 ms at 2951 x 236k, 0.169 -> 0.127 ms at 2951 x 59k; from 8192 queries
     // or 5 M rows on the 512-query form is faster, profiles/r1_knn_shapes.txt)
     static const int64_t q16_small = getenv("IMATCH_KNN_Q16_SMALL") ? atoll(getenv("IMATCH_KNN_Q16_SMALL")) : 6144;
-    const bool small16 = use16 && TNs == 128 && q->n <= q16_small && t->n_pad <= (1 << 20);
+    static const int form_env = getenv("IMATCH_KNN_FORM") ? atoi(getenv("IMATCH_KNN_FORM")) : 0;   // 4 / 8: force a form (A/B runs)
+    bool small16 = use16 && TNs == 128 && q->n <= q16_small && t->n_pad <= (1 << 20);
+    bool short8 = false;
+    // ... and from about 8e8 (query, row) pairs on -- a frame against a map of a quarter of a million rows or more -- the
+    // 512-query form with the 256-query form's first exchange: its stages are twice as long, so the per-tile and per-stage
+    // overheads weigh half as much (2951 x 1 M: 0.664 -> 0.531 ms, 5000 x 236k: 0.268 -> 0.242; 2951 x 236k level,
+    // below that the 256-query form wins: profiles/r2_knn_shapes.txt)
+    if (small16 && (form_env == 8 || (form_env == 0 && (double)q->n * (double)t->n_pad >= 8e8))) { small16 = false; short8 = true; }
+    if (form_env == 8 && use16 && TNs == 128 && q->n <= q16_small) { small16 = false; short8 = true; }
     if (small16) QB = 2;   // qtile below = 4 * 32 * 2 = 4 waves x 16 * 4 queries
     const int qtile = 4 * 32 * QB;
     const int64_t Qpad = q->n_pad;  // multiple of 1024, so of every qtile
@@ -906,7 +917,8 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
         // (rounded DOWN to a multiple of 8, so that the grid stays within two rounds of slots)
         // -- ONE round for the 256-query form: its launches are short (a frame against a map of well under a million
         // rows), a second, partly filled round would be a large part of them (1500 x 59k: 54 -> 44 us, 2951 x 59k: 76 -> 67)
-        int c = (((small16 ? 1 : 2) * slots + (small16 ? 0 : nQt - 1)) / nQt / 8) * 8;
+        const bool one_round = small16 || short8;
+        int c = (((one_round ? 1 : 2) * slots + (one_round ? 0 : nQt - 1)) / nQt / 8) * 8;
         // ... and chunks of at most 16k rows (4 MB, one XCD's L2): the query tiles that share a chunk then
         // re-read it from L2 however far apart they run, and the many short workgroups balance the tail
         c = std::max(c, (int)(((int64_t)nStages * TNs + 16383) / 16384 + 7) / 8 * 8);
@@ -966,6 +978,9 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
         if (use16) {
             if (small16)
                 hipLaunchKernelGGL((knn2_kernel16<4, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
+                                   stage0, list0, rot);
+            else if (short8)
+                hipLaunchKernelGGL((knn2_kernel16<8, 128, 7, true>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
                                    stage0, list0, rot);
             else if (TNs == 128 && xmask == 3)
                 hipLaunchKernelGGL((knn2_kernel16<8, 128, 3>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,

@@ -111,7 +111,7 @@ def _check_knn_at_scale(ctx, n, nq, n_dup, seed):
     eb, ei = _exact_top2(torch, q[pick], t)
     assert torch.equal(o[pick][:, [0, 2]], eb) and torch.equal(o[pick][:, [1, 3]], ei)
     # the CPU oracle on a window of the map: the queries whose source lies in it, against those rows only
-    w0, w1 = n // 2, n // 2 + 200_000
+    w0, w1 = n // 2, min(n, n // 2 + 200_000)
     inside = torch.nonzero((src >= w0) & (src < w1) & ((dup < 0) | (dup < w1))).flatten()[:256]
     if len(inside):
         fw = ctx.features_from_device_u8(t[w0:w1].data_ptr(), w1 - w0)
@@ -123,6 +123,11 @@ def _check_knn_at_scale(ctx, n, nq, n_dup, seed):
         fqw.free()
     ft.free()
     fq.free()
+
+
+def test_knn_one_frame_x_300k_rows_short_chunk_form(ctx):
+    """A frame's 3000 queries against 300 k rows: 9e8 pairs, the 512-query form with short chunks (merged first exchange)."""
+    _check_knn_at_scale(ctx, 300_000, 3000, 48, seed=10)
 
 
 def test_knn_config3_4096_queries_x_5M_rows(ctx):

@@ -43,9 +43,10 @@ def test_ragged_sizes(ctx, nq, nt):
 
 
 @pytest.mark.parametrize("nq,nt", [(513, 129), (6144, 16384), (6145, 30000), (8192, 16385), (7000, 100001), (12000, 50000),
-                                   (600, 127), (5000, 1 << 17)])
+                                   (600, 127), (5000, 1 << 17), (6000, 140001)])
 def test_kernel_path_boundaries_with_ties(ctx, nq, nt):
-    """Sizes either side of the launcher's switches (512 / 6144 queries, 128-row stages, 16 k-row chunks) with a fifth of
+    """Sizes either side of the launcher's switches (512 / 6144 queries, 128-row stages, 16 k-row chunks, 8e8 pairs: the
+    256-query form below, the short-chunk 512-query form above) with a fifth of
     the train rows copied from other rows: equal distances across chunk and row-quarter boundaries, lowest index first."""
     t = synth.synth_descriptors(nt, seed=nt)
     rng = np.random.default_rng(nq)
