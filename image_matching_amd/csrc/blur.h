@@ -230,18 +230,17 @@ blur_march_kernel(const void* __restrict__ src_, float* __restrict__ dst, float*
     };
 
     // ---- prologue: ring rows rel 0 .. 2R-1 = image rows y_start - R .. y_start + R - 1
-    {
-        const int yin = y_start - R;
-        if (chunk_fast(yin, R)) { issue(yin, R); land(R); } else fill_slow(yin, R);
-        __syncthreads();
-        row_pass(R, 0);
-        __syncthreads();
-    }
     const int nchunk = (y_end - y_start + CH - 1) / CH;
     bool have = false;   // registers hold the next chunk's rows
     {
-        const int yin = y_start + R;
-        if (chunk_fast(yin, NP)) { issue(yin, NP); have = true; }
+        const int yin = y_start - R;
+        if (chunk_fast(yin, R)) { issue(yin, R); land(R); } else fill_slow(yin, R);
+        // the first chunk's rows are asked for before the prologue's row pass, not after it: on a camera frame a workgroup
+        // marches through ONE chunk, and the second round trip to memory was a fifth of the kernel
+        if (chunk_fast(y_start + R, NP)) { issue(y_start + R, NP); have = true; }
+        __syncthreads();
+        row_pass(R, 0);
+        __syncthreads();
     }
     for (int s = 0; s < nchunk; ++s) {
         const int yin = y_start + R + CH * s;
@@ -306,4 +305,194 @@ static inline void blur_march_launch(hipStream_t st, const void* src, float* dst
     const int nseg = (nchunk + nt - 1) / nt, total = nstrip * nseg;
     hipLaunchKernelGGL((blur_march_kernel<R, W, UP, ABL>), dim3((unsigned)((total + 7) & ~7), 1, (unsigned)batch), dim3(256), 0, st,
                        src, dst, dec, rows, cols, ustride, gk, nt, nstrip, nseg, src_zs, zs);
+}
+
+// ---- three layers in one launch (camera frames) ----------------------------------------------------------------------
+// On a 640x480 frame every blur launch is a few microseconds of arithmetic behind a launch boundary, and layers 1..nl of
+// an octave are a dependent chain the next octave waits for. blur3_tile_kernel makes layers 1, 2 and 3 of an octave from
+// layer 0 in ONE launch: a workgroup owns a 64 x 32 tile, loads it with a halo of R1 + R2 + R3 pixels (reflect-101
+// applied to layer 0's coordinates), and runs the three separable blurs in LDS on shrinking regions -- layer 1 on the
+// tile + (R2 + R3), layer 2 on the tile + R3, layer 3 on the tile. Halo pixels are recomputed by the neighbouring tiles
+// (2 to 4 times the arithmetic of the marching kernel, on images where arithmetic is not what costs). Every in-image
+// value is the same ascending-tap fma chain over the same inputs as in blur_march_kernel, so the layers are
+// bit-identical; cells of an intermediate layer that lie OUTSIDE the image are overwritten with copies of their
+// reflect-101 sources before the next blur reads them (recomputing them from mirrored inputs would visit the taps in
+// mirrored order, which is not bit-identical).
+#define B3_TW 64
+#define B3_TH 32
+#define B3_NT 512   // threads: two waves per SIMD, so that one wave's LDS round trips hide behind the other's arithmetic
+
+template <int R>
+__device__ __forceinline__ void b3_row_pass(const float* __restrict__ S, float* __restrict__ Tm, const GK<R>& gk, int r0, int r1,
+                                            int c0, int c1, int P) {
+    constexpr int N = 2 * R + 1, RA = (R + 3) & ~3, OFF = RA - R, NV = (OFF + N + 3 + 3) / 4;
+    const int G = (c1 - c0) >> 2, items = (r1 - r0) * G;
+    for (int item = threadIdx.x; item < items; item += B3_NT) {
+        const int rr = item / G, g = item - rr * G;
+        const int r = r0 + rr, c = c0 + 4 * g;
+        const float4* src = (const float4*)(S + r * P + c - RA);
+        float v[NV * 4];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const float4 f = src[q];
+            v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+        }
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const float kk = gk.k[t <= R ? t : 2 * R - t];
+            a0 = fmaf(kk, v[OFF + t], a0);
+            a1 = fmaf(kk, v[OFF + t + 1], a1);
+            a2 = fmaf(kk, v[OFF + t + 2], a2);
+            a3 = fmaf(kk, v[OFF + t + 3], a3);
+        }
+        *(float4*)(Tm + r * P + c) = make_float4(a0, a1, a2, a3);
+    }
+}
+
+// D (in LDS) and, for cells of the workgroup's own tile inside the image, dst (+ dec) in memory
+template <int R>
+__device__ __forceinline__ void b3_col_pass(const float* __restrict__ Tm, float* __restrict__ D, const GK<R>& gk, int r0, int r1,
+                                            int c0, int c1, int P, float* __restrict__ dst, float* __restrict__ dec, int Y0,
+                                            int X0, int ty0, int tx0, int rows, int cols) {
+    constexpr int N = 2 * R + 1;
+    const int W = c1 - c0, items = ((r1 - r0) >> 2) * W;
+    for (int item = threadIdx.x; item < items; item += B3_NT) {
+        const int rg = item / W, cc = item - rg * W;
+        const int r = r0 + 4 * rg, c = c0 + cc;
+        const float* col = Tm + (r - R) * P + c;
+        float v[N + 3];
+#pragma unroll
+        for (int j = 0; j < N + 3; ++j) v[j] = col[j * P];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const float kk = gk.k[t <= R ? t : 2 * R - t];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[jj] = fmaf(kk, v[t + jj], acc[jj]);
+        }
+        const int gx = X0 + c;
+        const bool mine_x = gx >= tx0 && gx < tx0 + B3_TW && gx < cols;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            D[(r + jj) * P + c] = acc[jj];
+            const int gy = Y0 + r + jj;
+            if (mine_x && gy >= ty0 && gy < ty0 + B3_TH && gy < rows) {
+                dst[(size_t)gy * cols + gx] = acc[jj];
+                if (dec && !(gy & 1) && !(gx & 1) && (gy >> 1) < (rows >> 1) && (gx >> 1) < (cols >> 1))
+                    dec[(size_t)(gy >> 1) * (cols >> 1) + (gx >> 1)] = acc[jj];
+            }
+        }
+    }
+}
+
+// cells of the region outside the image <- their reflect-101 sources (inside the image and inside the region)
+// -- those within `reach` (the next blur's radius) of the image: nothing in-image reads the others, and their sources
+// could lie outside the region
+__device__ __forceinline__ void b3_mirror(float* __restrict__ D, int r0, int r1, int c0, int c1, int P, int Y0, int X0, int rows,
+                                          int cols, int reach) {
+    const int W = c1 - c0, n = (r1 - r0) * W;
+    for (int p = threadIdx.x; p < n; p += B3_NT) {
+        const int rr = p / W, cc = p - rr * W;
+        const int r = r0 + rr, c = c0 + cc;
+        const int gy = Y0 + r, gx = X0 + c;
+        const bool outside = (unsigned)gy >= (unsigned)rows || (unsigned)gx >= (unsigned)cols;
+        const bool near = gy >= -reach && gy < rows + reach && gx >= -reach && gx < cols + reach;
+        if (outside && near) {
+            const int sr = reflect101(gy, rows) - Y0, sc = reflect101(gx, cols) - X0;
+            if (sr >= r0 && sr < r1 && sc >= c0 && sc < c1) D[r * P + c] = D[sr * P + sc];
+        }
+    }
+}
+
+template <int R1, int R2, int R3>
+__global__ void __launch_bounds__(B3_NT)
+blur3_tile_kernel(const float* __restrict__ src, float* __restrict__ dst1, float* __restrict__ dst2, float* __restrict__ dst3,
+                  float* __restrict__ dec, int rows, int cols, GK<R1> k1, GK<R2> k2, GK<R3> k3, int tiles_x, size_t zs) {
+    constexpr int RA1 = (R1 + 3) & ~3;
+    constexpr int H1 = R2 + R3, H2 = R3;                     // halo of layers 1 and 2 around the tile
+    constexpr int HX1 = (H1 + 3) & ~3, HX2 = (H2 + 3) & ~3;  // ... in x, rounded up to whole float4 groups
+    constexpr int YB = H1 + R1, XB = HX1 + RA1;              // the tile's origin inside the buffers
+    constexpr int RB = B3_TH + 2 * YB, P = B3_TW + 2 * XB;
+    static_assert(((R2 + 3) & ~3) <= XB - HX2 && ((R3 + 3) & ~3) <= XB, "row-pass windows stay inside the buffer");
+    static_assert((B3_TH + 2 * H1) % 4 == 0 && (B3_TH + 2 * H2) % 4 == 0, "column pass walks four rows at a time");
+    __shared__ float4 sbuf4[RB * P / 4], tbuf4[RB * P / 4];
+    float* const S = (float*)sbuf4;
+    float* const Tm = (float*)tbuf4;
+    src = (const float*)((const char*)src + (size_t)blockIdx.z * zs);
+    dst1 = (float*)((char*)dst1 + (size_t)blockIdx.z * zs);
+    dst2 = (float*)((char*)dst2 + (size_t)blockIdx.z * zs);
+    dst3 = (float*)((char*)dst3 + (size_t)blockIdx.z * zs);
+    if (dec) dec = (float*)((char*)dec + (size_t)blockIdx.z * zs);
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int ty0 = ty * B3_TH, tx0 = tx * B3_TW;
+    const int Y0 = ty0 - YB, X0 = tx0 - XB;
+    // layer 0 with its halo: every buffer cell, through reflect-101 (a halo wider than a small image folds repeatedly)
+    // does any region poke out of the image? (workgroup-uniform)
+    const bool border = Y0 < 0 || Y0 + RB > rows || X0 < 0 || X0 + P > cols;
+    // (all of a round's loads are issued before its first LDS write: one load after the other was 30 of this kernel's 32 us)
+    if (!border && (cols & 3) == 0) {
+        constexpr int N4 = RB * P / 4, NL = (N4 + B3_NT - 1) / B3_NT;
+        float4 v[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int p4 = min((int)threadIdx.x + B3_NT * u, N4 - 1);
+            const int r = p4 / (P / 4), c4 = p4 - r * (P / 4);
+            v[u] = *(const float4*)(src + (size_t)(Y0 + r) * cols + (X0 + 4 * c4));
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int p4 = (int)threadIdx.x + B3_NT * u;
+            if (p4 < N4) sbuf4[p4] = v[u];
+        }
+    } else {
+        for (int p0 = threadIdx.x; p0 < RB * P; p0 += B3_NT * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int p = min(p0 + B3_NT * u, RB * P - 1);
+                const int r = p / P, c = p - r * P;
+                v[u] = src[(size_t)reflect101(Y0 + r, rows) * cols + reflect101(X0 + c, cols)];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int p = p0 + B3_NT * u;
+                if (p < RB * P) S[p] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    b3_row_pass<R1>(S, Tm, k1, YB - H1 - R1, YB + B3_TH + H1 + R1, XB - HX1, XB + B3_TW + HX1, P);
+    __syncthreads();
+    b3_col_pass<R1>(Tm, S, k1, YB - H1, YB + B3_TH + H1, XB - HX1, XB + B3_TW + HX1, P, dst1, nullptr, Y0, X0, ty0, tx0, rows, cols);
+    __syncthreads();
+    if (ty0 - H1 < 0 || ty0 + B3_TH + H1 > rows || tx0 - HX1 < 0 || tx0 + B3_TW + HX1 > cols) {
+        b3_mirror(S, YB - H1, YB + B3_TH + H1, XB - HX1, XB + B3_TW + HX1, P, Y0, X0, rows, cols, R2);
+        __syncthreads();
+    }
+    b3_row_pass<R2>(S, Tm, k2, YB - H2 - R2, YB + B3_TH + H2 + R2, XB - HX2, XB + B3_TW + HX2, P);
+    __syncthreads();
+    b3_col_pass<R2>(Tm, S, k2, YB - H2, YB + B3_TH + H2, XB - HX2, XB + B3_TW + HX2, P, dst2, nullptr, Y0, X0, ty0, tx0, rows, cols);
+    __syncthreads();
+    if (ty0 - H2 < 0 || ty0 + B3_TH + H2 > rows || tx0 - HX2 < 0 || tx0 + B3_TW + HX2 > cols) {
+        b3_mirror(S, YB - H2, YB + B3_TH + H2, XB - HX2, XB + B3_TW + HX2, P, Y0, X0, rows, cols, R3);
+        __syncthreads();
+    }
+    b3_row_pass<R3>(S, Tm, k3, YB - R3, YB + B3_TH + R3, XB, XB + B3_TW, P);
+    __syncthreads();
+    b3_col_pass<R3>(Tm, S, k3, YB, YB + B3_TH, XB, XB + B3_TW, P, dst3, dec, Y0, X0, ty0, tx0, rows, cols);
+}
+
+template <int R1, int R2, int R3>
+static inline void blur3_tile_launch(hipStream_t st, const float* src, float* dst1, float* dst2, float* dst3, float* dec, int rows,
+                                     int cols, const float* k1, const float* k2, const float* k3, int batch, size_t zs) {
+    GK<R1> g1;
+    GK<R2> g2;
+    GK<R3> g3;
+    for (int i = 0; i < 2 * R1 + 1; ++i) g1.k[i] = k1[i];
+    for (int i = 0; i < 2 * R2 + 1; ++i) g2.k[i] = k2[i];
+    for (int i = 0; i < 2 * R3 + 1; ++i) g3.k[i] = k3[i];
+    const int tiles_x = (cols + B3_TW - 1) / B3_TW, tiles_y = (rows + B3_TH - 1) / B3_TH;
+    hipLaunchKernelGGL((blur3_tile_kernel<R1, R2, R3>), dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch), dim3(B3_NT), 0, st,
+                       src, dst1, dst2, dst3, dec, rows, cols, g1, g2, g3, tiles_x, zs);
 }

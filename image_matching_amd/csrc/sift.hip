@@ -1597,9 +1597,23 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             }
         };
         bool have_l0 = true;   // layer 0 of octave o was written by the previous octave's layer-nl blur
+        // layers 1..3 of an octave in one launch where the radii are the default ones (blur3_tile_kernel)
+        float k3[3][2 * RT_MAXR + 1];
+        bool fuse3 = split && nl == 3;
+        for (int i = 1; i <= 3 && fuse3; ++i) {
+            static const int want_r[4] = {0, 5, 6, 8};
+            const int n = gauss_kernel(sig[i], k3[i - 1], 2 * RT_MAXR + 1);
+            if (n / 2 != want_r[i]) fuse3 = false;
+        }
+        if (const char* e = getenv("IMATCH_SIFT_FUSE3")) fuse3 = fuse3 && atoi(e) != 0;        // experiments
         for (int o = 0; o < o_tail && split; ++o) {
             const int rows = T.rows[o], cols = T.cols[o];
-            for (int i = 1; i <= nl; ++i) {
+            if (fuse3) {
+                float* dec = o + 1 < o_tail ? T.gauss[o + 1][0] : nullptr;
+                blur3_tile_launch<5, 6, 8>(ctx->stream, T.gauss[o][0], T.gauss[o][1], T.gauss[o][2], T.gauss[o][3], dec, rows, cols,
+                                           k3[0], k3[1], k3[2], batch, zs);
+            }
+            for (int i = 1; i <= nl && !fuse3; ++i) {
                 float* dec = (i == nl && o + 1 < o_tail) ? T.gauss[o + 1][0] : nullptr;
                 rc = gaussian_blur(ctx, ctx->stream, T.gauss[o][i - 1], nullptr, 0, 0, T.gauss[o][i], dec, d_tmp, rows, cols, sig[i],
                                    batch, zs, nullptr);
