@@ -801,6 +801,28 @@ static int features_pack(imatch_ctx* ctx, imatch_features* f, const T* src_dev) 
     return IMATCH_OK;
 }
 
+// pad rows of a set whose real rows (bf16 values, norm, -|t|^2/2) were written by their producer (describe_kernel)
+__global__ void pad_rows_kernel(int64_t n, int64_t n_pad, uint16_t* __restrict__ dst, float* __restrict__ norm,
+                                float* __restrict__ hneg, int* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = n + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;
+    if (row >= n_pad) return;
+    ((uint32_t*)dst)[row * 64 + lane] = 0u;
+    if (lane == 0) {
+        norm[row] = INFINITY;
+        hneg[row] = -INFINITY;
+    }
+}
+
+int imatch_features_pad_dev(imatch_ctx* ctx, imatch_features* f) {
+    const unsigned grid = (unsigned)((f->n_pad - f->n + 3) / 4 + 1);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, f->n, f->n_pad, f->desc, f->norm, f->hneg, f->flag);
+    HIP_TRY(ctx, hipGetLastError());
+    f->integral = 1;
+    return IMATCH_OK;
+}
+
 // u8 rows are integral by type: no flag to read back, so this only queues work on the stream
 int imatch_features_pack_u8_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev) {
     HIP_TRY(ctx, hipMemsetAsync(f->flag, 0, 256, ctx->stream));

@@ -953,10 +953,10 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
 #define DESC_HIST (6 * 6 * 10)
 template <int WPK>
 __global__ void __launch_bounds__(256)
-describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first_octave, uint8_t* __restrict__ desc,
-                size_t zs) {
+describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first_octave, uint16_t* __restrict__ rows_bf16,
+                float* __restrict__ norm, float* __restrict__ hneg, size_t zs) {
     const size_t zo = (size_t)blockIdx.z * zs;
-    kps = ZP(kps); desc = ZP(desc);
+    kps = ZP(kps);
     const int n_kp = seg.off[blockIdx.z + 1] - seg.off[blockIdx.z];
     constexpr int GROUPS = 4 / WPK, GL = 64 * WPK;
     __shared__ unsigned long long hist[GROUPS][DESC_HIST];
@@ -1128,11 +1128,23 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nrm2 += __shfl_xor(nrm2, o);
     nrm2 = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
+    // The quantised descriptor goes straight into the matcher's row format (what pack_rows_kernel made of the u8 rows in a
+    // pass of its own: 0.2 ms of a 64-frame batch): bf16 values -- exact for integers 0..255, the upper half of the f32
+    // pattern --, the squared norm and -|t|^2/2 of the row (integer sums below 2^24: any order gives the same float).
     if (active) {
+        const size_t row = (size_t)seg.off[blockIdx.z] + (size_t)id;
+        float s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int q = __float2int_rn(v[e] * nrm2);
-            desc[(size_t)id * 128 + lane + 64 * e] = (uint8_t)min(max(q, 0), 255);
+            const float q = (float)min(max(__float2int_rn(v[e] * nrm2), 0), 255);
+            rows_bf16[row * 128 + lane + 64 * e] = (uint16_t)(__float_as_uint(q) >> 16);
+            s2 += q * q;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+        if (lane == 0) {
+            norm[row] = s2;
+            hneg[row] = -0.5f * s2;
         }
     }
 }
@@ -1892,17 +1904,17 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             const int wpk = wpk_env ? wpk_env : 4;
             if (wpk == 4)
                 hipLaunchKernelGGL(describe_kernel<4>, dim3(max_k, 1, batch), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted,
-                                   seg, first_octave, d_desc, zs);
+                                   seg, first_octave, f->desc, f->norm, f->hneg, zs);
             else if (wpk == 2)
                 hipLaunchKernelGGL(describe_kernel<2>, dim3((max_k + 1) / 2, 1, batch), dim3(256), 0, ctx->stream, T,
-                                   (const KpRec*)d_sorted, seg, first_octave, d_desc, zs);
+                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->hneg, zs);
             else
                 hipLaunchKernelGGL(describe_kernel<1>, dim3((max_k + 3) / 4, 1, batch), dim3(256), 0, ctx->stream, T,
-                                   (const KpRec*)d_sorted, seg, first_octave, d_desc, zs);
+                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->hneg, zs);
             HIP_TRY(ctx, hipGetLastError());
         }
-        // bf16 rows + norms of the concatenated set, queued (u8 rows are integral by type)
-        rc = batch == 1 ? imatch_features_pack_u8_dev(ctx, f, d_desc) : imatch_features_pack_u8_seg_dev(ctx, f, d_desc, &seg, zs);
+        // the set's pad rows and flag (u8 rows are integral by type)
+        rc = imatch_features_pad_dev(ctx, f);   // the rows themselves came from describe_kernel
         if (rc) { imatch_features_free(f); return rc; }
         // the host copy of the keypoint table is written while the GPU works on the descriptors (it reads the pinned rows
         // the upload queued above is reading too)
