@@ -428,13 +428,25 @@ def main():
     # 13.8 ms step). One tail in flight at most; every tail has finished before a timed region ends (drain_tail).
     pipeline = B > 1 and n_streams == 1 and os.environ.get("IMATCH_BENCH_PIPELINE", "1") != "0"
     tail_ctx = im.Context(local_rank) if pipeline else None
-    tail_thread = [None]
     tail_err = []
+    import queue
+    tail_q = queue.Queue()
+
+    def tail_worker():          # one long-lived thread: starting a thread per step cost ~0.1 ms of GPU idling per step
+        while True:
+            job = tail_q.get()
+            try:
+                if job is None:
+                    return
+                batch_tail(*job)
+            except Exception as e:      # surfaced by the next drain_tail
+                tail_err.append(e)
+            finally:
+                tail_q.task_done()
 
     def drain_tail():
-        if tail_thread[0] is not None:
-            tail_thread[0].join()
-            tail_thread[0] = None
+        if pipeline:
+            tail_q.join()
         if tail_err:
             raise tail_err[0]
 
@@ -460,6 +472,9 @@ def main():
                 stats["found"] += int(found.sum())
         return H
 
+    if pipeline:
+        threading.Thread(target=tail_worker, daemon=True).start()
+
     def step_batch(i, record=False, lane=0):
         cx, mt = ctxs[lane], matchers[lane]
         fr = batches_d[(i * n_streams + lane) % len(batches_d)]
@@ -477,14 +492,7 @@ def main():
         if not pipeline:
             return batch_tail(cx, f, offs, gq, gt, goff, i, record, pyr_ms, knn_ms, q_launch_now, nq)
         drain_tail()
-
-        def work():
-            try:
-                batch_tail(tail_ctx, f, offs, gq, gt, goff, i, record, pyr_ms, knn_ms, q_launch_now, nq)
-            except Exception as e:      # surfaced by the next drain_tail
-                tail_err.append(e)
-        tail_thread[0] = threading.Thread(target=work)
-        tail_thread[0].start()
+        tail_q.put((tail_ctx, f, offs, gq, gt, goff, i, record, pyr_ms, knn_ms, q_launch_now, nq))
         return None
 
     def run_steps(n, record):

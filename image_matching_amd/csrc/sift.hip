@@ -80,11 +80,20 @@ struct imatch_sift_state {
     hipEvent_t ev_fork, ev_join;
     hipEvent_t ev_oct[MAX_OCT];
     bool have_ev_oct;
+    // A batch's sorted records (7 MB for 64 frames) go to the host on a stream of their own, beside the descriptor kernel:
+    // the host needs only the counters to launch it, the records for the keypoint table it fills afterwards.
+    hipStream_t copy;
+    hipEvent_t ev_sorted;
 };
 
 void imatch_sift_state_free(imatch_ctx* ctx) {
     if (!ctx || !ctx->sift) return;
     if (ctx->sift->arena) (void)hipFree(ctx->sift->arena);
+    if (ctx->sift->copy) {
+        (void)hipStreamSynchronize(ctx->sift->copy);
+        (void)hipEventDestroy(ctx->sift->ev_sorted);
+        (void)hipStreamDestroy(ctx->sift->copy);
+    }
     if (ctx->sift->side) {
         (void)hipStreamSynchronize(ctx->sift->side);
         (void)hipEventDestroy(ctx->sift->ev_fork);
@@ -1760,9 +1769,30 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if (rc) return rc;
         int* h_cnt = (int*)ctx->hs;                              // [batch][4]
         KpRec* h_kp = (KpRec*)((char*)ctx->hs + cnt_bytes);      // [batch][kp_hint]
+        // ends the record copy on the second stream on every way out of this attempt
+        struct CopyGuard {
+            hipStream_t s;
+            bool pending;
+            hipError_t wait() { const hipError_t e = pending ? hipStreamSynchronize(s) : hipSuccess; pending = false; return e; }
+            ~CopyGuard() { (void)wait(); }
+        } rec_copy{nullptr, false};
+        const bool copy_aside = dev_sort && (size_t)batch * kp_hint * sizeof(KpRec) >= ((size_t)1 << 20);
         HIP_TRY(ctx, hipMemcpy2DAsync(h_cnt, 16, d_cnt, zs, 16, (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), dev_sort ? d_sorted : d_kp, zs,
-                                      (size_t)kp_hint * sizeof(KpRec), (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
+        if (copy_aside) {
+            if (!S->copy) {
+                HIP_TRY(ctx, hipStreamCreateWithFlags(&S->copy, hipStreamNonBlocking));
+                HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_sorted, hipEventDisableTiming));
+            }
+            HIP_TRY(ctx, hipEventRecord(S->ev_sorted, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(S->copy, S->ev_sorted, 0));
+            rec_copy.s = S->copy;
+            rec_copy.pending = true;
+            HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), d_sorted, zs, (size_t)kp_hint * sizeof(KpRec),
+                                          (size_t)batch, hipMemcpyDeviceToHost, S->copy));
+        } else {
+            HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), dev_sort ? d_sorted : d_kp, zs,
+                                          (size_t)kp_hint * sizeof(KpRec), (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
+        }
         const bool timing = getenv("IMATCH_TIMING") != nullptr;
         const double t_a = now_ms();
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1800,6 +1830,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             }
         }
         if (refetch || max_fetch > kp_hint) {  // the guess was short: fetch everything again at the right width
+            HIP_TRY(ctx, rec_copy.wait());
             kp_hint = std::max(kp_hint, max_fetch);
             rc = imatch_hs_reserve(ctx, cnt_bytes + (size_t)batch * kp_hint * sizeof(KpRec));  // may move hs
             if (rc) return rc;
@@ -1918,6 +1949,10 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if (rc) { imatch_features_free(f); return rc; }
         // the host copy of the keypoint table is written while the GPU works on the descriptors (it reads the pinned rows
         // the upload queued above is reading too)
+        {
+            const hipError_t e = rec_copy.wait();
+            if (e != hipSuccess) { imatch_features_free(f); return imatch_set_err(ctx, IMATCH_EHIP, "record copy: %s", hipGetErrorString(e)); }
+        }
         if (batch >= 4) imatch_parallel_for(ctx, batch, fill_table);
         else
             for (int b = 0; b < batch; ++b) fill_table(b);
