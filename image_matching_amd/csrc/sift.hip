@@ -884,11 +884,13 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
     KpRec* stage = stage_all[wave];
     int n_staged = 0;
     const int n_ref = min(*n_ref_dev, ref_cap);
-    for (int base = blockIdx.x * 4; base < n_ref; base += gridDim.x * 4) {  // workgroup-uniform trip count
-        const int id = base + wave;
-        const bool active = id < n_ref;
+    // Every wave walks its own keypoints: its histogram and staging rows are its own, so the phases below are ordered by
+    // wave-level fences, not workgroup barriers (seven of them per keypoint, with the four waves' window sizes differing,
+    // were a third of this kernel).
+    for (int id = blockIdx.x * 4 + wave; id < n_ref; id += gridDim.x * 4) {  // wave-uniform trip count
+        const bool active = true;
         if (lane < n) hacc[wave][lane] = 0ull;
-        __syncthreads();
+        wave_lds_fence();
         RefinedKp k;
         if (active) {
             k = ref[id];
@@ -899,8 +901,12 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
             const float sigma = 1.5f * scl_octv;
             const float expf_scale = -1.f / (2.f * sigma * sigma);
             const int side = 2 * radius + 1;
+            // p / side through the float reciprocal: (p + 0.5) / side is at least 0.5 / side away from an integer, far more
+            // than the rounding of the product for any window that fits an image
+            const float inv_side = __builtin_amdgcn_rcpf((float)side);
             for (int p = lane; p < side * side; p += 64) {
-                const int i = p / side - radius, j = p % side - radius;
+                const int pi = (int)(((float)p + 0.5f) * inv_side);
+                const int i = pi - radius, j = p - pi * side - radius;
                 const int y = k.r + i, x = k.c + j;
                 if (y <= 0 || y >= rows - 1 || x <= 0 || x >= cols - 1) continue;
                 const float dx = img[(size_t)y * cols + x + 1] - img[(size_t)y * cols + x - 1];
@@ -914,14 +920,14 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
                 atomicAdd(&hacc[wave][bin], (unsigned long long)(long long)__float2int_rn(w * mag * FIX_SCALE));
             }
         }
-        __syncthreads();
+        wave_lds_fence();
         if (lane < n) hsm[wave][lane + 2] = (float)(long long)hacc[wave][lane] * FIX_INV;
-        __syncthreads();
+        wave_lds_fence();
         if (lane == 0) {
             float* th = &hsm[wave][2];
             th[-1] = th[n - 1]; th[-2] = th[n - 2]; th[n] = th[0]; th[n + 1] = th[1];
         }
-        __syncthreads();
+        wave_lds_fence();
         float hv = 0.f;
         if (lane < n) {
             const float* th = &hsm[wave][2];
@@ -931,9 +937,9 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
         float mx = lane < n ? hv : -FLT_MAX;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        __syncthreads();
+        wave_lds_fence();
         if (lane < n) hsm[wave][lane] = hv;  // smoothed histogram, plain indexing from here
-        __syncthreads();
+        wave_lds_fence();
         bool peak = false;
         KpRec o;
         if (active && lane < n) {
@@ -950,7 +956,7 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
             }
         }
         stage_append<KpRec, ORI_STAGE>(stage, n_staged, peak, o, out, cap, count);
-        __syncthreads();  // hsm/hacc are rewritten by the next keypoint
+        wave_lds_fence();  // hsm/hacc are rewritten by the next keypoint
     }
     stage_flush_block(stage, n_staged, wcnt, out, cap, count);
 }
