@@ -614,9 +614,10 @@ extern "C" int imatch_dbg_tail_trace(long long* out) {
 // SPLIT: one workgroup per octave (blockIdx.x), for single frames, where this kernel is a third of the scale-space chain:
 // octave o + 1 needs only layer nl of octave o, so its workgroup starts as soon as that layer is in the global pyramid
 // (a flag per octave in the image's counter block, release / acquire at agent scope) while octave o's workgroup goes on
-// with its last two layers and scans. A consumer has a higher workgroup index than its producer and workgroups are
-// dispatched in index order, so a waiting workgroup never keeps its producer off the chip. A batch keeps the one-workgroup
-// walk: there the waiting workgroups would hold CUs that other images' kernels can use.
+// with its last two layers and scans. No dispatch order is assumed: the launcher uses this form only for grids of at most
+// 32 workgroups (one CU each, of 256), so every workgroup becomes resident whatever the waiting ones do -- kernels of other
+// streams that hold CUs meanwhile finish without any help from this one. A batch keeps the one-workgroup walk: there the
+// waiting workgroups would hold CUs that other images' kernels can use, and the grid would no longer fit the chip.
 template <int R1, int R2, int R3, int R4, int R5, bool SPLIT>
 __global__ void __launch_bounds__(1024)
 pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* __restrict__ cand, int cap,
