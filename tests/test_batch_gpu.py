@@ -93,6 +93,48 @@ def test_full_batch_at_the_bench_shape_and_odd_sizes(ctx, scene):
     f.free()
 
 
+def test_largest_batch_128_images_through_the_whole_chain_and_129_refused(ctx, scene):
+    """IMATCH_MAX_BATCH images (bench.py's step at configs[1]) through extraction, one kNN launch, the batched ratio test and
+    the batched homography: a sample of the images as the single-image chain gives them; one image more is refused."""
+    m, frames5 = scene
+    dev = torch.device("cuda", 0)
+    f_map = ctx.sift_extract(m)
+    map_xy = f_map.download(descriptors=False)[0][:, :2]
+    frames = [frames5[i % 5] for i in range(128)]
+    frames[77] = np.ascontiguousarray(frames5[3][:, ::-1])
+    stack = torch.from_numpy(np.stack(frames)).to(dev)
+    f, offs = ctx.sift_extract_batch_dev(stack.data_ptr(), 128, 240 * 320, 240, 320, 320)
+    kp, desc = f.download()
+    assert len(offs) == 129 and offs[-1] == len(f)
+    out4 = torch.empty((len(f), 4), dtype=torch.int32, device=dev)
+    ctx.knn2_dev(f, f_map, out4.data_ptr())
+    gq, gt, gd, goff = ctx.ratio_batch_dev(out4.data_ptr(), offs, 0.7)
+    src = np.concatenate([kp[offs[b] + gq[goff[b]:goff[b + 1]], :2] for b in range(128)])
+    H, mask, found = ctx.homography_batch(src, map_xy[gt], goff, 0.1, seeds=np.arange(128))
+    for b in (0, 64, 77, 127):
+        one = ctx.sift_extract(frames[b])
+        kp1, desc1 = one.download()
+        assert np.array_equal(kp[offs[b]:offs[b + 1]], kp1) and np.array_equal(desc[offs[b]:offs[b + 1]], desc1), b
+        idx, dist = ctx.knn2(one, f_map)
+        o4 = out4[offs[b]:offs[b + 1]].cpu().numpy()
+        assert np.array_equal(o4[:, [1, 3]], idx)
+        o1 = torch.empty((len(one), 4), dtype=torch.int32, device=dev)
+        ctx.knn2_dev(one, f_map, o1.data_ptr())
+        q1, t1, d1 = ctx.ratio_dev(o1.data_ptr(), len(one), 0.7)
+        assert np.array_equal(gq[goff[b]:goff[b + 1]], q1) and np.array_equal(gt[goff[b]:goff[b + 1]], t1)
+        if len(q1) >= 4:
+            H1, _ = ctx.homography(kp1[q1, :2], map_xy[t1], 0.1, seed=b)
+            assert (H1 is None) == (not found[b])
+            if H1 is not None:
+                assert np.array_equal(H[b], H1)
+        one.free()
+    f.free()
+    big = torch.zeros((129, 64 * 64), dtype=torch.uint8, device=dev)
+    with pytest.raises(Exception):
+        ctx.sift_extract_batch_dev(big.data_ptr(), 129, 64 * 64, 64, 64, 64)
+    f_map.free()
+
+
 def test_match_chain_batch_equals_single(ctx, scene):
     m, frames = scene
     dev = torch.device("cuda", 0)
@@ -128,7 +170,7 @@ def test_batch_limits(ctx, scene):
     dev = torch.device("cuda", 0)
     t = torch.from_numpy(frames[0]).to(dev)
     with pytest.raises(im.ImatchError):
-        ctx.sift_extract_batch_dev(t.data_ptr(), 65, 240 * 320, 240, 320, 320)
+        ctx.sift_extract_batch_dev(t.data_ptr(), 129, 240 * 320, 240, 320, 320)
     with pytest.raises(im.ImatchError):
         ctx.sift_extract_batch_dev(t.data_ptr(), 2, 100, 240, 320, 320)
     # empty segments
