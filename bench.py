@@ -6,7 +6,7 @@ Metric (BASELINE.json): frames/sec of the full chain CLAHE -> SIFT -> kNN(k=2)+r
 reference's map.png is not in its tree, so the "full map" is the seeded synthetic 8192x8192 orthomap of
 SURVEY.md 8d). Gdist/s of the kNN stage is reported beside it.
 
-A step = every rank takes ONE BATCH of --batch frames (default 128 at c1, 64 at c3, 32 at c5; already in HBM as one
+A step = every rank takes ONE BATCH of --batch frames (default 256 at c1, 64 at c3, 32 at c5; already in HBM as one
 [B,480,640] tensor)
 through the batched entry points: extract (every kernel launched once for the batch) -> one kNN launch
 over all the batch's keypoints against the whole map -> ratio -> homography per frame (iff > 10 good
@@ -210,7 +210,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per step and GPU, taken through the batched entry points (one launch per stage for "
                          "the whole batch, one kNN launch over all frames' keypoints); 1 = the single-frame calls; "
-                         "default 128 (c3: 64, c5: 32); at most 128")
+                         "default 256 (c3: 64, c5: 32); at most 256")
     ap.add_argument("--streams", type=int, default=1,
                     help="frames in flight per GPU: each has its own context (stream + arena) and host thread; a step is "
                          "then one frame per stream")
@@ -298,7 +298,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     workload = args.workload if args.workload != "auto" else ("c1" if world == 1 else "c3")
     replicated_frames = workload == "c5"
-    B = args.batch if args.batch > 0 else (32 if workload == "c5" else 128 if workload == "c1" else 64)
+    B = args.batch if args.batch > 0 else (32 if workload == "c5" else 256 if workload == "c1" else 64)
 
     import image_matching_amd as im
     from image_matching_amd import sharded, synth

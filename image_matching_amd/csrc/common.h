@@ -62,7 +62,7 @@ struct imatch_features {
 #define IMATCH_ROW_PAD 1024
 
 // Batched extraction: rows [off[b], off[b+1]) of a concatenated set belong to image b.
-#define IMATCH_MAX_BATCH 128
+#define IMATCH_MAX_BATCH 256
 struct imatch_segtab { int n; int off[IMATCH_MAX_BATCH + 1]; };
 
 int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out);

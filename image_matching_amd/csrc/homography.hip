@@ -83,10 +83,12 @@ __host__ __device__ static inline bool hypothesis(const double* pts, int n, uint
 // segment) holds n_b = off[b+1] - off[b] correspondences, its normalised points at pts + 4 * off[b]
 // doubles ([4][n_b]: sx, sy, dx, dy) and fpts + 4 * off[b] floats, its MSAC scale in inv_tau2[b] and
 // its sampler seed in seeds[b].
+// (seeds and scales travel in the uploaded block behind the points: with 256 segments they would not fit the 4 KB of
+// kernel arguments beside the offsets)
 struct HomoSeg {
     imatch_segtab seg;
-    float inv_tau2[IMATCH_MAX_BATCH];
-    unsigned long long seeds[IMATCH_MAX_BATCH];
+    const float* inv_tau2;                 // [segments], device
+    const unsigned long long* seeds;       // [segments], device
 };
 
 __global__ void __launch_bounds__(256)
@@ -202,19 +204,25 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t dbytes = sizeof(double) * 4 * (size_t)ntot, fbytes = sizeof(float) * 4 * (size_t)ntot;
     const size_t kbytes = 8 * (size_t)nseg;
-    int rc = imatch_hs_reserve(ctx, dbytes + fbytes + kbytes + 64);
+    // pinned / device block: points f64, points f32, seeds, scales (uploaded in one copy), then the result keys
+    const size_t sbytes = 8 * (size_t)nseg, tbytes = (4 * (size_t)nseg + 7) & ~(size_t)7;
+    const size_t up_bytes = dbytes + fbytes + sbytes + tbytes;
+    int rc = imatch_hs_reserve(ctx, up_bytes + kbytes + 64);
     if (rc) return rc;
-    rc = imatch_ws_reserve(ctx, dbytes + fbytes + kbytes + 256);
+    rc = imatch_ws_reserve(ctx, up_bytes + kbytes + 256);
     if (rc) return rc;
     double* Pall = (double*)ctx->hs;
     float* Fall = (float*)((char*)ctx->hs + dbytes);
+    unsigned long long* h_seeds = (unsigned long long*)((char*)ctx->hs + dbytes + fbytes);
+    float* h_itau2 = (float*)((char*)ctx->hs + dbytes + fbytes + sbytes);
+    memset(h_itau2, 0, tbytes);
     HomoSeg hs;
     memset(&hs, 0, sizeof(hs));
     hs.seg = seg;
     std::vector<double> Ts(3 * (size_t)nseg), Td(3 * (size_t)nseg), tau((size_t)nseg, 0.0);
     for (int b = 0; b < nseg; ++b) {
         const int n = seg.off[b + 1] - seg.off[b];
-        hs.seeds[b] = seeds[b];
+        h_seeds[b] = seeds[b];
         if (n < 4) continue;
         const float* sp = src + 2 * (size_t)seg.off[b];
         const float* dp = dst + 2 * (size_t)seg.off[b];
@@ -230,18 +238,20 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
         }
         for (int i = 0; i < 4 * n; ++i) F[i] = (float)P[i];
         tau[b] = fmax(thr, HOMO_TAU_FLOOR) * td[0];
-        hs.inv_tau2[b] = (float)(1.0 / (tau[b] * tau[b]));
+        h_itau2[b] = (float)(1.0 / (tau[b] * tau[b]));
     }
     char* dev = (char*)ctx->ws;
-    unsigned long long* d_best = (unsigned long long*)(dev + dbytes + fbytes);
-    HIP_TRY(ctx, hipMemcpyAsync(dev, ctx->hs, dbytes + fbytes, hipMemcpyHostToDevice, ctx->stream));
+    unsigned long long* d_best = (unsigned long long*)(dev + up_bytes);
+    hs.seeds = (const unsigned long long*)(dev + dbytes + fbytes);
+    hs.inv_tau2 = (const float*)(dev + dbytes + fbytes + sbytes);
+    HIP_TRY(ctx, hipMemcpyAsync(dev, ctx->hs, up_bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_best, 0, kbytes, ctx->stream));
     // one problem: single-wave workgroups, or its 4096 hypotheses sit on 16 of the 256 CUs
     const int wg = nseg >= 8 ? 256 : 64;
     hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / wg, nseg), dim3(wg), 0, ctx->stream,
                        (const double*)dev, (const float*)(dev + dbytes), hs, d_best);
     HIP_TRY(ctx, hipGetLastError());
-    unsigned long long* h_key = (unsigned long long*)((char*)ctx->hs + dbytes + fbytes);  // pinned: no staging copy
+    unsigned long long* h_key = (unsigned long long*)((char*)ctx->hs + up_bytes);  // pinned: no staging copy
     HIP_TRY(ctx, hipMemcpyAsync(h_key, d_best, kbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     auto finish = [&](int b) {

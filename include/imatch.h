@@ -61,7 +61,7 @@ int imatch_features_from_host_f32(imatch_ctx* ctx, const float* desc, int64_t n,
 int imatch_features_from_host_u8(imatch_ctx* ctx, const uint8_t* desc, int64_t n, int d, imatch_features** out);
 /* Same, from a u8 [n][128] matrix already in device memory (a torch tensor's data_ptr). */
 int imatch_features_from_device_u8(imatch_ctx* ctx, const uint8_t* desc_dev, int64_t n, int d, imatch_features** out);
-/* Same, from n_seg (<= 128) row blocks in device memory: block b holds counts[b] rows of 128 bytes at
+/* Same, from n_seg (<= 256) row blocks in device memory: block b holds counts[b] rows of 128 bytes at
  * desc_dev + b * seg_pitch bytes (the layout an all-gather of per-rank query blocks of a fixed capacity leaves: each
  * rank's rows at the start of its slot). The set is the blocks' rows back to back, without the unused tail of any
  * slot. Only queues work on the context's stream (u8 rows are integral by type: nothing to read back). No reference
@@ -156,7 +156,7 @@ int imatch_sift_extract_dev(imatch_ctx* ctx, const uint8_t* img_dev, int h, int 
                             const imatch_sift_params* params, imatch_features** out);
 /* Batched form (no reference counterpart: the reference handles one /photo message at a time,
  * PF:159-224; this is BASELINE configs[4], many frames per launch). n_img equally sized u8 images in
- * device memory, image b at img_dev + b * img_pitch bytes (n_img <= 128). Every kernel runs once for
+ * device memory, image b at img_dev + b * img_pitch bytes (n_img <= 256). Every kernel runs once for
  * the whole batch. The result is ONE descriptor set with the images' rows back to back:
  * offsets[b] .. offsets[b+1] (n_img + 1 entries) are image b's rows and keypoint records; each
  * image's rows are exactly what imatch_sift_extract_dev returns for it. No image copy is kept. */

@@ -93,8 +93,32 @@ def test_full_batch_at_the_bench_shape_and_odd_sizes(ctx, scene):
     f.free()
 
 
-def test_largest_batch_128_images_through_the_whole_chain_and_129_refused(ctx, scene):
-    """IMATCH_MAX_BATCH images (bench.py's step at configs[1]) through extraction, one kNN launch, the batched ratio test and
+def test_largest_batch_256_frames_at_the_bench_shape(ctx, scene):
+    """IMATCH_MAX_BATCH = 256 frames of 640 x 480 in one call (bench.py's step at configs[1]): a sample of the images, the
+    first and the last included, as the single-image call gives them."""
+    m, _ = scene
+    dev = torch.device("cuda", 0)
+    base = [synth.synth_frame(m, 60 + i, size=(480, 640), scale_range=(0.5, 0.6))[0] for i in range(5)]
+    frames = [base[i % 5] for i in range(256)]
+    frames[200] = np.ascontiguousarray(base[1][::-1])
+    stack = torch.from_numpy(np.stack(frames)).to(dev)
+    f, offs = ctx.sift_extract_batch_dev(stack.data_ptr(), 256, 480 * 640, 480, 640, 640)
+    kp, desc = f.download()
+    assert len(offs) == 257 and offs[-1] == len(f)
+    singles = {}
+    for b in (0, 1, 127, 128, 199, 200, 201, 254, 255):
+        key = b % 5 if b != 200 else b
+        if key not in singles:
+            one = ctx.sift_extract(frames[b])
+            singles[key] = one.download()
+            one.free()
+        kp1, desc1 = singles[key]
+        assert np.array_equal(kp[offs[b]:offs[b + 1]], kp1) and np.array_equal(desc[offs[b]:offs[b + 1]], desc1), b
+    f.free()
+
+
+def test_batch_of_128_images_through_the_whole_chain_and_257_refused(ctx, scene):
+    """128 images (half of IMATCH_MAX_BATCH) through extraction, one kNN launch, the batched ratio test and
     the batched homography: a sample of the images as the single-image chain gives them; one image more is refused."""
     m, frames5 = scene
     dev = torch.device("cuda", 0)
@@ -129,9 +153,9 @@ def test_largest_batch_128_images_through_the_whole_chain_and_129_refused(ctx, s
                 assert np.array_equal(H[b], H1)
         one.free()
     f.free()
-    big = torch.zeros((129, 64 * 64), dtype=torch.uint8, device=dev)
+    big = torch.zeros((257, 64 * 64), dtype=torch.uint8, device=dev)
     with pytest.raises(Exception):
-        ctx.sift_extract_batch_dev(big.data_ptr(), 129, 64 * 64, 64, 64, 64)
+        ctx.sift_extract_batch_dev(big.data_ptr(), 257, 64 * 64, 64, 64, 64)
     f_map.free()
 
 
@@ -170,7 +194,7 @@ def test_batch_limits(ctx, scene):
     dev = torch.device("cuda", 0)
     t = torch.from_numpy(frames[0]).to(dev)
     with pytest.raises(im.ImatchError):
-        ctx.sift_extract_batch_dev(t.data_ptr(), 129, 240 * 320, 240, 320, 320)
+        ctx.sift_extract_batch_dev(t.data_ptr(), 257, 240 * 320, 240, 320, 320)
     with pytest.raises(im.ImatchError):
         ctx.sift_extract_batch_dev(t.data_ptr(), 2, 100, 240, 320, 320)
     # empty segments
