@@ -1167,17 +1167,22 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
 
 // ---- KeyPoint12_LessThan sort + removeDuplicatedSorted + first-octave rescale on the device ------------------------------
 // A camera frame has a few thousand keypoint records: fetching them, sorting them on the host and sending them back held
-// the GPU idle for ~115 us of a 0.7 ms frame. Two short kernels do it where the records lie.
-//   kp_rank_kernel    a record's place in the sorted list is the number of records that come before it: every workgroup
-//                     holds ALL keys (order-preserving bits of x and y, 8 B each) in LDS, sixteen lanes share a record
-//                     and count a sixteenth of the keys each (a broadcast LDS read, a 64-bit compare and an add per
-//                     key); records of equal (x, y) -- the several orientations of one point -- are ordered by the full
-//                     comparator (size desc, angle asc, response desc, octave desc), read from the records themselves.
-//   kp_dedupe_kernel  one workgroup per image: duplicates (equal x, y, size, angle) are neighbours now and are dropped,
-//                     the rest rescaled to the input image's frame and written back to back.
-// Above the launch's limit (the previous extraction's count plus a margin, at most SORT_CAP) the kernels report -1 and
-// the host's radix sort runs on the raw records.
+// the GPU idle for ~115 us of a 0.7 ms frame. kp_sort_kernel does it where the records lie, one 1024-thread workgroup per
+// image, everything in LDS:
+//   1. keys (order-preserving bits of x and y, 8 B per record) -> LDS;
+//   2. a counting sort on 256 buckets of x (x is the leading key and the bucket number is monotone in it): histogram by
+//      LDS atomics, prefix, record numbers scattered bucket by bucket;
+//   3. a record's place = its bucket's start + the number of bucket-mates that come before it (a dozen compares; records
+//      of equal (x, y) -- the several orientations of one point -- go through the full comparator: size desc, angle asc,
+//      response desc, octave desc, read from the records themselves);
+//   4. duplicates (equal x, y, size, angle) are neighbours now and are dropped, the rest rescaled to the input image's
+//      frame and written back to back (flags, a workgroup scan, strided writes).
+// (The first version ranked every record against ALL others, 16 or 4 lanes per record over many workgroups: 14 us for a
+// frame, 0.23 ms for a 64-frame batch.) Above the launch's limit (the previous extraction's count plus a margin, at most
+// SORT_CAP) the kernel reports -1 and the host's radix sort runs on the raw records.
 #define SORT_CAP 8192
+#define SORT_NB 256
+#define SORT_LDS_BYTES (SORT_CAP * (8 + 2 + 2 + 1 + 2) + (2 * SORT_NB + 2 + 16) * 4)
 
 __device__ __forceinline__ unsigned ord_bits(float f) {
     const unsigned u = __float_as_uint(f);
@@ -1194,72 +1199,92 @@ __device__ __forceinline__ bool kp_tie_before(const KpRec* __restrict__ rec, int
     return ia < ib;
 }
 
-template <int TPR>   // lanes per record: 16 for one frame (many short workgroups), 4 for a batch (fewer copies of the keys)
-__global__ void __launch_bounds__(256)
-kp_rank_kernel(const KpRec* __restrict__ rec, const int* __restrict__ n_dev, int limit, int* __restrict__ order, size_t zs) {
-    const size_t zo = (size_t)blockIdx.z * zs;
-    rec = ZP(rec); n_dev = ZP(n_dev); order = ZP(order);
-    extern __shared__ unsigned long long rank_keys[];
-    const int n = *n_dev;                  // limit = the keys the launch has LDS for (<= SORT_CAP)
-    constexpr int RPW = 256 / TPR;         // records per workgroup and round
-    if (n > limit || (int)blockIdx.x * RPW >= n) return;
-    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 16) {   // sixteen loads in flight per lane: the fill is all latency
-        float2 xy[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = min(i0 + 256 * u, n - 1);
-            xy[u] = *(const float2*)&rec[i].x;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = i0 + 256 * u;
-            if (i < n) rank_keys[i] = ((unsigned long long)ord_bits(xy[u].x) << 32) | ord_bits(xy[u].y);
-        }
-    }
-    __syncthreads();
-    const int part = threadIdx.x % TPR;
-    for (int i0 = blockIdx.x * RPW; i0 < n; i0 += gridDim.x * RPW) {   // (whole waves take the shuffles below)
-        const int i = min(i0 + (int)threadIdx.x / TPR, n - 1);
-        const unsigned long long mine = rank_keys[i];
-        int before = 0;
-        int j = part;
-        for (; j + 7 * TPR < n; j += 8 * TPR) {   // eight LDS reads in flight: one wave per SIMD has nothing else to hide them
-            unsigned long long k[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) k[u] = rank_keys[j + u * TPR];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (k[u] < mine) ++before;
-                else if (k[u] == mine && j + u * TPR != i && kp_tie_before(rec, j + u * TPR, i)) ++before;
-            }
-        }
-        for (; j < n; j += TPR) {
-            const unsigned long long k = rank_keys[j];
-            if (k < mine) ++before;
-            else if (k == mine && j != i && kp_tie_before(rec, j, i)) ++before;
-        }
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) before += __shfl_xor(before, o);
-        if (part == 0 && i0 + (int)threadIdx.x / TPR < n) order[before] = i;
-    }
-}
-
 __global__ void __launch_bounds__(1024)
-kp_dedupe_kernel(const KpRec* __restrict__ rec, const int* __restrict__ n_dev, int limit, const int* __restrict__ order,
-                 KpRec* __restrict__ out, int* __restrict__ k_out, int first_octave, size_t zs) {
+kp_sort_kernel(const KpRec* __restrict__ rec, const int* __restrict__ n_dev, int limit, float bucket_scale,
+               KpRec* __restrict__ out, int* __restrict__ k_out, int first_octave, size_t zs) {
     const size_t zo = (size_t)blockIdx.z * zs;
-    rec = ZP(rec); n_dev = ZP(n_dev); order = ZP(order); out = ZP(out); k_out = ZP(k_out);
-    __shared__ int wsum[16];
+    rec = ZP(rec); n_dev = ZP(n_dev); out = ZP(out); k_out = ZP(k_out);
+    extern __shared__ unsigned long long sort_lds[];
+    unsigned long long* const keys = sort_lds;                                   // [SORT_CAP]
+    unsigned short* const member = (unsigned short*)(keys + SORT_CAP);            // record numbers, bucket by bucket
+    unsigned short* const order = member + SORT_CAP;                              // record number at every sorted place
+    unsigned short* const off_s = order + SORT_CAP;                               // output place of every sorted place
+    unsigned char* const keep_s = (unsigned char*)(off_s + SORT_CAP);
+    int* const hist = (int*)(keep_s + SORT_CAP);                                  // [SORT_NB] counts, then fill cursors
+    int* const start = hist + SORT_NB;                                            // [SORT_NB + 1]
+    int* const wsum = start + SORT_NB + 2;                                        // [16]
     const int tid = threadIdx.x;
     const int n = *n_dev;
-    if (n > limit) {                       // the rank kernel did not run either
+    if (n > limit) {
         if (tid == 0) *k_out = -1;
         return;
     }
-    // keep flags: place i against place i - 1, strided over the threads so that the loads of the E rounds overlap
     constexpr int E = SORT_CAP / 1024;
-    __shared__ unsigned char keep_s[SORT_CAP];
-    __shared__ unsigned short off_s[SORT_CAP];
+    // 1. + 2a. keys and bucket counts (all of a thread's loads in flight before the first use)
+    float2 xy[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = min(tid + 1024 * e, max(n - 1, 0));
+        xy[e] = *(const float2*)&rec[i].x;
+    }
+    if (tid < SORT_NB) hist[tid] = 0;
+    __syncthreads();
+    int bkt[E], pos[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < n) {
+            keys[i] = ((unsigned long long)ord_bits(xy[e].x) << 32) | ord_bits(xy[e].y);
+            bkt[e] = min(max((int)(xy[e].x * bucket_scale), 0), SORT_NB - 1);
+            pos[e] = atomicAdd(&hist[bkt[e]], 1);
+        }
+    }
+    __syncthreads();
+    // 2b. bucket starts: exclusive prefix of the 256 counts by the first four waves
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        int v = tid < SORT_NB ? hist[tid] : 0, incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (tid < SORT_NB && lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        if (tid < SORT_NB) {
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += wsum[w];
+            start[tid] = base + incl - v;
+            if (tid == SORT_NB - 1) start[SORT_NB] = base + incl;
+        }
+    }
+    __syncthreads();
+    // 2c. members of every bucket side by side
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < n) member[start[bkt[e]] + pos[e]] = (unsigned short)i;
+    }
+    __syncthreads();
+    // 3. place = bucket start + bucket-mates before me
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < n) {
+            const unsigned long long mine = keys[i];
+            const int j0 = start[bkt[e]], j1 = start[bkt[e] + 1];
+            int before = j0;
+            for (int j = j0; j < j1; ++j) {
+                const int m = member[j];
+                const unsigned long long k = keys[m];
+                if (k < mine) ++before;
+                else if (k == mine && m != i && kp_tie_before(rec, m, i)) ++before;
+            }
+            order[before] = (unsigned short)i;
+        }
+    }
+    __syncthreads();
+    // 4. keep flags (place i against place i - 1), scan, compaction
     KpRec mine_rec[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -1277,8 +1302,7 @@ kp_dedupe_kernel(const KpRec* __restrict__ rec, const int* __restrict__ n_dev, i
         keep_s[i] = kp;
     }
     __syncthreads();
-    // exclusive scan over consecutive runs of E places per thread
-    const int base = tid * E;
+    const int base = tid * E;   // consecutive runs of E places per thread for the scan
     int mine = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) mine += keep_s[base + e];
@@ -1751,21 +1775,14 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if (dev_sort) {
             static bool attr_set[64] = {false};
             if (!attr_set[ctx->device & 63]) {
-                HIP_TRY(ctx, hipFuncSetAttribute((const void*)kp_rank_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 SORT_CAP * 8));
-                HIP_TRY(ctx, hipFuncSetAttribute((const void*)kp_rank_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 SORT_CAP * 8));
+                HIP_TRY(ctx, hipFuncSetAttribute((const void*)kp_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 SORT_LDS_BYTES));
                 attr_set[ctx->device & 63] = true;
             }
-            int* d_order = (int*)d_cand;       // the candidates are spent too
-            if (batch < 8)
-                hipLaunchKernelGGL(kp_rank_kernel<16>, dim3((n_sort + 15) / 16, 1, batch), dim3(256), (size_t)n_sort * 8,
-                                   ctx->stream, (const KpRec*)d_kp, (const int*)(d_cnt + 2), n_sort, d_order, zs);
-            else
-                hipLaunchKernelGGL(kp_rank_kernel<4>, dim3((n_sort + 63) / 64, 1, batch), dim3(256), (size_t)n_sort * 8,
-                                   ctx->stream, (const KpRec*)d_kp, (const int*)(d_cnt + 2), n_sort, d_order, zs);
-            hipLaunchKernelGGL(kp_dedupe_kernel, dim3(1, 1, batch), dim3(1024), 0, ctx->stream, (const KpRec*)d_kp,
-                               (const int*)(d_cnt + 2), n_sort, (const int*)d_order, d_sorted, d_cnt + 3, first_octave, zs);
+            // x of a record lies in [0, 2w) (base-octave coordinates): 256 buckets over that range
+            hipLaunchKernelGGL(kp_sort_kernel, dim3(1, 1, batch), dim3(1024), SORT_LDS_BYTES, ctx->stream, (const KpRec*)d_kp,
+                               (const int*)(d_cnt + 2), n_sort, (float)SORT_NB / (float)bcols, d_sorted, d_cnt + 3, first_octave,
+                               zs);
             HIP_TRY(ctx, hipGetLastError());
         }
         // ---- the extraction's one synchronisation: the counters and (a guess of) the records of every image
