@@ -173,7 +173,7 @@ def test_calls_right_after_an_extraction_do_not_disturb_its_descriptors(ctx):
 
 
 def test_device_sort_and_its_host_fallback_agree_with_the_oracle():
-    """Frames are sorted, deduplicated and rescaled on the device (kp_rank_kernel / kp_dedupe_kernel), launched for the
+    """Frames are sorted, deduplicated and rescaled on the device (kp_sort_kernel), launched for the
     previous extraction's keypoint count plus a margin; an image with more records than that goes through the host's
     radix sort in the same call. Both must give the oracle's list, record for record: a fresh context sees a small image
     first (few keypoints: a small launch), then a 1024^2 image (several thousand: host fallback), then the same image
