@@ -912,9 +912,9 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
                 if (y <= 0 || y >= rows - 1 || x <= 0 || x >= cols - 1) continue;
                 const float dx = img[(size_t)y * cols + x + 1] - img[(size_t)y * cols + x - 1];
                 const float dy = img[(size_t)(y - 1) * cols + x] - img[(size_t)(y + 1) * cols + x];
-                const float w = expf((i * i + j * j) * expf_scale);
-                const float ori = atan2_deg(dy, dx);
-                const float mag = sqrtf(dx * dx + dy * dy);
+                const float w = __expf((i * i + j * j) * expf_scale);
+                const float ori = atan2_deg_lean(dy, dx);
+                const float mag = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
                 int bin = __float2int_rn((n / 360.f) * ori);
                 if (bin >= n) bin -= n;
                 if (bin < 0) bin += n;
