@@ -68,7 +68,7 @@ struct imatch_sift_state {
     size_t arena_bytes;
     PyrTable T;
     int h, w;
-    int ref_hint, kp_hint;  // list lengths of the previous extraction: launch-grid and download-size guesses
+    int cand_hint, ref_hint, kp_hint;  // list lengths of the previous extraction: launch-grid and download-size guesses
     // Octave 1 needs only layer nl of octave 0, and an octave's six kernels depend on one another in a
     // chain: on large images octave 0's layers nl+1, nl+2 and scan (main stream) run beside ALL later octaves
     // (this second stream, forked after octave 0's layer nl, joined before the refinement). The later
@@ -1759,7 +1759,10 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         }
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
         // ---- refine + orientation are queued behind the scan without waiting for its count
-        hipLaunchKernelGGL(refine_kernel, dim3(std::min((cap + 255) / 256, 1024), 1, batch), dim3(256), 0, ctx->stream, T,
+        // (grid from the previous extraction's candidate count -- the kernel strides: sized by the list's CAPACITY, a batch
+        // launched forty thousand workgroups of which a few hundred found a candidate)
+        const int cand_hint = std::min(cap, S->cand_hint > 0 ? S->cand_hint : cap);
+        hipLaunchKernelGGL(refine_kernel, dim3(std::min(std::max((cand_hint + 255) / 256, 16), 1024), 1, batch), dim3(256), 0, ctx->stream, T,
                            (const uint2*)d_cand, (const int*)d_cnt, cap, (float)P->contrast_threshold,
                            (float)P->edge_threshold, (float)P->sigma, d_ref, d_cnt + 1, zs);
         const int ref_hint = S->ref_hint > 0 ? S->ref_hint : 4096;
@@ -1835,6 +1838,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             cap = max_kp;
             continue;
         }
+        S->cand_hint = max_cand + max_cand / 4 + 256;
         S->ref_hint = max_ref + max_ref / 4 + 256;
         S->kp_hint = max_kp + max_kp / 4 + 1024;
         std::vector<int> n_kp((size_t)batch);
