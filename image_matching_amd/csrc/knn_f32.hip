@@ -3,7 +3,7 @@
 // M-SURF descriptors the checked-in detector produces. These are not small integers, so the bf16 MFMA kernel of knn.hip
 // (exact only for 0..255 values) does not apply; this one computes sum_k (q_k - t_k)^2 in f32 in index order, one
 // sequential chain per pair -- the order of oracle_knn2 -- so distances, indices and ties are bit-identical to the oracle.
-// fp32 VALU-bound: 3 instructions per pair and dimension, operands from LDS tiles stored dimension-major.
+// fp32 VALU-bound: 1.5 packed instructions per pair and dimension, operands from LDS tiles stored dimension-major.
 #include <math.h>
 #include "common.h"
 
@@ -11,6 +11,7 @@
 #define KF_TT 64
 
 struct kf_top2 { float d1, d2; int j1, j2; };
+typedef float kf2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void kf_insert(kf_top2& b, float dd, int j) {   // (dist, index) lexicographic
     if (dd < b.d1 || (dd == b.d1 && j < b.j1)) { b.d2 = b.d1; b.j2 = b.j1; b.d1 = dd; b.j1 = j; }
@@ -26,10 +27,28 @@ knn2_f32_kernel(const float* __restrict__ q, int64_t nq, const float* __restrict
     float* ts = lds + (size_t)d * KF_TQ;  // [d][64]
     const int tid = threadIdx.x, tq = tid & 15, tt = tid >> 4;
     const int64_t q0 = (int64_t)blockIdx.x * KF_TQ;
-    for (int i = tid; i < KF_TQ * d; i += 256) {
-        const int r = i / d, k = i - r * d;
-        qs[k * KF_TQ + r] = q0 + r < nq ? q[(q0 + r) * d + k] : 0.f;
-    }
+    // Tiles go into LDS dimension-major. With consecutive lanes on consecutive DIMENSIONS of a row every lane of a wave wrote
+    // the same LDS bank (addresses 64 floats apart: a 64-way conflict, 40 % of the kernel); consecutive lanes on consecutive
+    // ROWS write side by side, and each lane's 16-byte global reads walk its row, whose lines stay in the vector cache.
+    auto load_tile = [&](float* dstl, const float* __restrict__ src, int64_t r0, int64_t n_rows) {
+        if ((d & 3) == 0) {
+            const int d4 = d >> 2;
+            for (int i = tid; i < 64 * d4; i += 256) {
+                const int r = i & 63, kq = i >> 6;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r0 + r < n_rows) v = *(const float4*)(src + (r0 + r) * d + 4 * kq);
+                dstl[(4 * kq) * 64 + r] = v.x; dstl[(4 * kq + 1) * 64 + r] = v.y;
+                dstl[(4 * kq + 2) * 64 + r] = v.z; dstl[(4 * kq + 3) * 64 + r] = v.w;
+            }
+        } else {
+            for (int i = tid; i < 64 * d; i += 256) {
+                const int r = i & 63, k = i >> 6;
+                dstl[k * 64 + r] = r0 + r < n_rows ? src[(r0 + r) * d + k] : 0.f;
+            }
+        }
+    };
+    static_assert(KF_TQ == 64 && KF_TT == 64, "load_tile walks 64-row tiles");
+    load_tile(qs, q, q0, nq);
     kf_top2 best[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) { best[a].d1 = best[a].d2 = INFINITY; best[a].j1 = best[a].j2 = -1; }
@@ -38,34 +57,32 @@ knn2_f32_kernel(const float* __restrict__ q, int64_t nq, const float* __restrict
         const int64_t t0 = (tile0 + ti) * KF_TT;
         if (t0 >= nt) break;
         __syncthreads();
-        for (int i = tid; i < KF_TT * d; i += 256) {
-            const int r = i / d, k = i - r * d;
-            ts[k * KF_TT + r] = t0 + r < nt ? t[(t0 + r) * d + k] : 0.f;
-        }
+        load_tile(ts, t, t0, nt);
         __syncthreads();
-        float s[4][4];
+        // two train rows per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_add_f32: the same subtraction, product and
+        // sum per pair as the scalar form, in the same order -- 1.5 instead of 3 instructions per pair and dimension)
+        kf2 s2[4][2];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) s[a][b] = 0.f;
+        for (int a = 0; a < 4; ++a) { s2[a][0] = kf2{0.f, 0.f}; s2[a][1] = kf2{0.f, 0.f}; }
         for (int k = 0; k < d; ++k) {
             const float4 qa = *(const float4*)(qs + k * KF_TQ + tq * 4);
             const float4 tb = *(const float4*)(ts + k * KF_TT + tt * 4);
-            const float qv[4] = {qa.x, qa.y, qa.z, qa.w}, tv[4] = {tb.x, tb.y, tb.z, tb.w};
+            const float qv[4] = {qa.x, qa.y, qa.z, qa.w};
+            const kf2 t01 = {tb.x, tb.y}, t23 = {tb.z, tb.w};
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float e = qv[a] - tv[b];
-                    s[a][b] += e * e;
-                }
+            for (int a = 0; a < 4; ++a) {
+                const kf2 q2 = {qv[a], qv[a]};
+                const kf2 e01 = q2 - t01, e23 = q2 - t23;
+                s2[a][0] += e01 * e01;
+                s2[a][1] += e23 * e23;
+            }
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {   // ascending train index within the thread
             const int64_t j = t0 + tt * 4 + b;
             if (j < nt) {
 #pragma unroll
-                for (int a = 0; a < 4; ++a) kf_insert(best[a], sqrtf(s[a][b]), (int)j);
+                for (int a = 0; a < 4; ++a) kf_insert(best[a], sqrtf(s2[a][b >> 1][b & 1]), (int)j);
             }
         }
     }
