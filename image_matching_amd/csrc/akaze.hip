@@ -54,6 +54,7 @@ struct imatch_akaze_state {
     int* n_cand;             // device counter
     float* cand;             // device [cap][AK_CAND_FLOATS]; its own allocation, grown when a scan overflows it
     int cand_cap;
+    int cand_hint;           // candidates of the previous call + a margin: how many records the first download takes
     float* kp_dev;           // device [kp_cap][8]: x, y, size, angle, response, octave, level, pad; own allocation
     float* desc_dev;         // device [kp_cap][64], behind kp_dev
     int kp_cap;
@@ -1033,10 +1034,20 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     };
     const auto t_enq = now();
     // candidates -> host
+    // (the count and a guess of the records -- the previous call's count plus a margin -- in ONE synchronisation; the rest,
+    // if the guess was short, in a second one)
     int n_cand = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_cand, S->n_cand, 4, hipMemcpyDeviceToHost, st));
+    const int guess = std::min(S->cand_cap, S->cand_hint > 0 ? S->cand_hint : 8192);
+    const size_t cnt_b = 256, guess_b = (size_t)guess * AK_CAND_FLOATS * 4;
+    rc = imatch_hs_reserve(ctx, cnt_b + guess_b);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs, S->n_cand, 4, hipMemcpyDeviceToHost, st));
+    if (guess) HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->hs + cnt_b, S->cand, guess_b, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (n_cand > S->cand_cap) {   // the scan counted them all: grow the list and scan again (the planes are still there)
+    n_cand = *(const int*)ctx->hs;
+    bool have_guess = true;
+    if (n_cand > S->cand_cap) {
+        have_guess = false;   // the scan counted them all: grow the list and scan again (the planes are still there)
         rc = akaze_grow_lists(ctx, n_cand + n_cand / 8, 0);
         if (rc) return rc;
         rc = scan();
@@ -1047,13 +1058,16 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     }
     const float* raw = nullptr;   // the records stay in the pinned block until the levels are built from them
     const auto t_gpu = now();
+    S->cand_hint = n_cand + n_cand / 4 + 256;
     if (n_cand) {
         const size_t rb = (size_t)n_cand * AK_CAND_FLOATS * 4;
-        rc = imatch_hs_reserve(ctx, rb);
-        if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->hs, S->cand, rb, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        raw = (const float*)ctx->hs;
+        if (!have_guess || n_cand > guess) {   // everything again at the right width (the block may move)
+            rc = imatch_hs_reserve(ctx, cnt_b + rb);
+            if (rc) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->hs + cnt_b, S->cand, rb, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+        }
+        raw = (const float*)((char*)ctx->hs + cnt_b);
     }
     const auto t_dl = now();
     std::vector<ak_level_pts> LP((size_t)S->n_levels);
