@@ -357,6 +357,8 @@ ak_area_kernel(const float* __restrict__ src, int srows, int scols, float* __res
 #define AK_SMALL_PX 19200
 #define AK_SMALL_LDS_FLOATS 40000   // 2 px + 4 cols must fit: 160 000 bytes of the CU's 160 KB
 #define AK_SMALL_PT 19      // pixels per thread at 1024 threads
+typedef float ak_f2 __attribute__((ext_vector_type(2)));
+template <bool PAIRS>   // PAIRS (even cols): a thread steps two neighbouring pixels at a time, 64-bit LDS accesses and packed f32 math
 __global__ void __launch_bounds__(1024)
 ak_level_small_kernel(const float* __restrict__ prev, int prows, int pcols, int halve, int fast, double scale_x, double scale_y,
                       int rows, int cols, ak_taps g5,
@@ -418,47 +420,99 @@ ak_level_small_kernel(const float* __restrict__ prev, int prows, int pcols, int 
     // registers (0 where OpenCV's edge rules drop the neighbour, all four 0 at the corners: the dropped terms are then
     // exact zeros at the places the source leaves them out) and F's LDS becomes the second image plane, so a step is
     // five LDS reads per pixel and one barrier.
-    float cR[AK_SMALL_PT], cL[AK_SMALL_PT], cD[AK_SMALL_PT], cU[AK_SMALL_PT];
-    {
-        // (y, x) of pixel tid + 1024 j by stepping: 1024 = qs * cols + rs
-        const int qs = 1024 / cols, rs = 1024 - qs * cols;
-        int y = tid / cols, x = tid - y * cols;
+    if (PAIRS) {
+        // pixel pair q = tid + 1024 j holds pixels 2q, 2q + 1 (same row: cols is even). Per step and pair: three 64-bit and
+        // two 32-bit LDS reads, one 64-bit write and 13 packed instructions -- the scalar form's subtractions, products and
+        // sums, in its order, for both pixels at once (the scalar form: ten reads, two writes, 26 instructions).
+        constexpr int NPAIR = (AK_SMALL_PT + 1) / 2;
+        ak_f2 cR[NPAIR], cL[NPAIR], cD[NPAIR], cU[NPAIR];
+        const int npair = px >> 1, hc = cols >> 1;
+        {
+            const int qs = 1024 / hc, rs = 1024 - qs * hc;   // (y, pair column) of pair tid + 1024 j by stepping
+            int y = tid / hc, xh = tid - y * hc;
 #pragma unroll
-        for (int j = 0; j < AK_SMALL_PT; ++j) {
-            const int p = tid + j * 1024;
-            const int pc = min(p, px - 1);   // threads beyond the plane compute on its last pixel and never store
-            const bool x0 = x == 0, x1 = x == cols - 1, y0 = y == 0, y1 = y == rows - 1;
-            const bool corner = (x0 || x1) && (y0 || y1);
-            const float fc = F[pc];
-            // F has guard rows too: the loads need no conditions, the selects drop what OpenCV's edge rules drop
-            const float r = fc + F[pc + 1], l = fc + F[pc - 1], d = fc + F[pc + cols], u = fc + F[pc - cols];
-            cR[j] = (x1 || corner) ? 0.f : r;
-            cL[j] = (x0 || corner) ? 0.f : l;
-            cD[j] = (y1 || corner) ? 0.f : d;
-            cU[j] = (y0 || corner) ? 0.f : u;
-            x += rs; y += qs;
-            if (x >= cols) { x -= cols; ++y; }
-            asm volatile("" ::: "memory");   // one pixel's operands in flight at a time: 76 registers hold the sums
-        }
-    }
-    __syncthreads();
-    float* B = F;
-    for (int st = 0; st < nsteps; ++st) {
-        const float step = tau[st] * 0.5f;
-#pragma unroll
-        for (int j = 0; j < AK_SMALL_PT; ++j) {
-            const int p = tid + j * 1024;
-            if (p < px) {
-                // a dropped neighbour has a zero coefficient: whatever finite value sits there stands in for it
-                const float tc = A[p];
-                const float tr = A[p + 1], tl = A[p - 1], td = A[p + cols], tu = A[p - cols];
-                const float sum = cR[j] * (tr - tc) + cL[j] * (tl - tc) + cD[j] * (td - tc) + cU[j] * (tu - tc);
-                const float stepv = sum * step;
-                B[p] = tc + stepv;
+            for (int j = 0; j < NPAIR; ++j) {
+                const int q = min(tid + j * 1024, npair - 1);
+                const int pc = 2 * q;
+                const bool y0 = y == 0, y1 = y == rows - 1;
+                const bool xa0 = xh == 0, xb1 = xh == hc - 1;          // first pixel at x = 0, second at x = cols - 1
+                const float fa = F[pc], fb = F[pc + 1];
+                const float ra = fa + fb, la = fa + F[pc - 1], da = fa + F[pc + cols], ua = fa + F[pc - cols];
+                const float rb = fb + F[pc + 2], lb = fb + fa, db = fb + F[pc + 1 + cols], ub = fb + F[pc + 1 - cols];
+                const bool ca = xa0 && (y0 || y1), cb = xb1 && (y0 || y1);
+                cR[j] = ak_f2{ca ? 0.f : ra, (xb1 || cb) ? 0.f : rb};
+                cL[j] = ak_f2{(xa0 || ca) ? 0.f : la, cb ? 0.f : lb};
+                cD[j] = ak_f2{(y1 || ca) ? 0.f : da, (y1 || cb) ? 0.f : db};
+                cU[j] = ak_f2{(y0 || ca) ? 0.f : ua, (y0 || cb) ? 0.f : ub};
+                xh += rs; y += qs;
+                if (xh >= hc) { xh -= hc; ++y; }
+                asm volatile("" ::: "memory");
             }
         }
         __syncthreads();
-        float* t_ = A; A = B; B = t_;
+        float* B = F;
+        for (int st = 0; st < nsteps; ++st) {
+            const float stepf = tau[st] * 0.5f;
+            const ak_f2 step = {stepf, stepf};
+#pragma unroll
+            for (int j = 0; j < NPAIR; ++j) {
+                const int q = tid + j * 1024;
+                if (q < npair) {
+                    const int p = 2 * q;
+                    const ak_f2 tc = *(const ak_f2*)(A + p);
+                    const ak_f2 td = *(const ak_f2*)(A + p + cols), tu = *(const ak_f2*)(A + p - cols);
+                    const ak_f2 tr = {tc.y, A[p + 2]}, tl = {A[p - 1], tc.x};
+                    const ak_f2 sum = cR[j] * (tr - tc) + cL[j] * (tl - tc) + cD[j] * (td - tc) + cU[j] * (tu - tc);
+                    const ak_f2 stepv = sum * step;
+                    *(ak_f2*)(B + p) = tc + stepv;
+                }
+            }
+            __syncthreads();
+            float* t_ = A; A = B; B = t_;
+        }
+    } else {
+        float cR[AK_SMALL_PT], cL[AK_SMALL_PT], cD[AK_SMALL_PT], cU[AK_SMALL_PT];
+        {
+            // (y, x) of pixel tid + 1024 j by stepping: 1024 = qs * cols + rs
+            const int qs = 1024 / cols, rs = 1024 - qs * cols;
+            int y = tid / cols, x = tid - y * cols;
+#pragma unroll
+            for (int j = 0; j < AK_SMALL_PT; ++j) {
+                const int p = tid + j * 1024;
+                const int pc = min(p, px - 1);   // threads beyond the plane compute on its last pixel and never store
+                const bool x0 = x == 0, x1 = x == cols - 1, y0 = y == 0, y1 = y == rows - 1;
+                const bool corner = (x0 || x1) && (y0 || y1);
+                const float fc = F[pc];
+                // F has guard rows too: the loads need no conditions, the selects drop what OpenCV's edge rules drop
+                const float r = fc + F[pc + 1], l = fc + F[pc - 1], d = fc + F[pc + cols], u = fc + F[pc - cols];
+                cR[j] = (x1 || corner) ? 0.f : r;
+                cL[j] = (x0 || corner) ? 0.f : l;
+                cD[j] = (y1 || corner) ? 0.f : d;
+                cU[j] = (y0 || corner) ? 0.f : u;
+                x += rs; y += qs;
+                if (x >= cols) { x -= cols; ++y; }
+                asm volatile("" ::: "memory");   // one pixel's operands in flight at a time: 76 registers hold the sums
+            }
+        }
+        __syncthreads();
+        float* B = F;
+        for (int st = 0; st < nsteps; ++st) {
+            const float step = tau[st] * 0.5f;
+#pragma unroll
+            for (int j = 0; j < AK_SMALL_PT; ++j) {
+                const int p = tid + j * 1024;
+                if (p < px) {
+                    // a dropped neighbour has a zero coefficient: whatever finite value sits there stands in for it
+                    const float tc = A[p];
+                    const float tr = A[p + 1], tl = A[p - 1], td = A[p + cols], tu = A[p - cols];
+                    const float sum = cR[j] * (tr - tc) + cL[j] * (tl - tc) + cD[j] * (td - tc) + cU[j] * (tu - tc);
+                    const float stepv = sum * step;
+                    B[p] = tc + stepv;
+                }
+            }
+            __syncthreads();
+            float* t_ = A; A = B; B = t_;
+        }
     }
     for (int p = tid; p < px; p += 1024) Lt[p] = A[p];
 }
@@ -871,7 +925,9 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
         HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(ak_ori_dj), dj, sizeof dj));
         HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(ak_ori_w), wt, sizeof wt));
     }
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)ak_level_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)ak_level_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     AK_SMALL_LDS_FLOATS * 4));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)ak_level_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      AK_SMALL_LDS_FLOATS * 4));
     return IMATCH_OK;
 }
@@ -957,6 +1013,7 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
                            300, S->hist);
         hipLaunchKernelGGL(ak_kc_kernel, dim3(1), dim3(64), 0, st, S->hist, S->hmax, 300, total, 0.7f, P->n_octaves, S->kc);
     }
+    static const bool small_pairs = !(getenv("IMATCH_AKAZE_PAIRS") && atoi(getenv("IMATCH_AKAZE_PAIRS")) == 0);   // A/B runs
     for (int i = 1; i < S->n_levels; ++i) {
         ak_level* e = &S->lv[i];
         ak_level* p = &S->lv[i - 1];
@@ -967,9 +1024,14 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
         const int fast = fabs(sc_x - 2.0) < 2.220446049250313e-16 && fabs(sc_y - 2.0) < 2.220446049250313e-16;
         if (e->rows * e->cols <= AK_SMALL_PX && 2 * e->rows * e->cols + 4 * e->cols <= AK_SMALL_LDS_FLOATS && e->rows >= 2 &&
             e->cols >= 2) {
-            hipLaunchKernelGGL(ak_level_small_kernel, dim3(1), dim3(1024), ((size_t)2 * e->rows * e->cols + 4 * e->cols) * 4, st, p->Lt, p->rows,
-                               p->cols, e->octave > p->octave ? 1 : 0, fast, sc_x, sc_y, e->rows, e->cols, g5, S->kc, e->octave, e->nsteps,
-                               S->tau_dev + (size_t)i * AK_MAX_STEPS, e->Lt, e->Lsmooth);
+            if ((e->cols & 1) == 0 && small_pairs)
+                hipLaunchKernelGGL(ak_level_small_kernel<true>, dim3(1), dim3(1024), ((size_t)2 * e->rows * e->cols + 4 * e->cols) * 4, st, p->Lt, p->rows,
+                                   p->cols, e->octave > p->octave ? 1 : 0, fast, sc_x, sc_y, e->rows, e->cols, g5, S->kc, e->octave, e->nsteps,
+                                   S->tau_dev + (size_t)i * AK_MAX_STEPS, e->Lt, e->Lsmooth);
+            else
+                hipLaunchKernelGGL(ak_level_small_kernel<false>, dim3(1), dim3(1024), ((size_t)2 * e->rows * e->cols + 4 * e->cols) * 4, st, p->Lt, p->rows,
+                                   p->cols, e->octave > p->octave ? 1 : 0, fast, sc_x, sc_y, e->rows, e->cols, g5, S->kc, e->octave, e->nsteps,
+                                   S->tau_dev + (size_t)i * AK_MAX_STEPS, e->Lt, e->Lsmooth);
             continue;
         }
         // one launch per step, alternating between e->Lt and tmpA so that the last step writes e->Lt; the first step
