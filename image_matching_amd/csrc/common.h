@@ -47,10 +47,10 @@ struct imatch_pool_block {
 struct imatch_features {
     imatch_ctx* ctx;
     int64_t n;        // valid rows
-    int64_t n_pad;    // rows allocated, multiple of IMATCH_ROW_PAD; pad rows are zero with norm +inf
-    uint16_t* desc;   // bf16 [n_pad][128], device
-    float* norm;      // f32 [n_pad] squared L2 norms (exact integers for integral sets), device
-    float* hneg;      // f32 [n_pad] = -norm/2 (pad rows: -inf): the MFMA accumulator's start value; norm + n_pad
+    int64_t n_pad;    // rows allocated, multiple of IMATCH_ROW_PAD; pad rows are zero bytes with tneg = -2^24
+    int8_t* desc;     // int8 [n_pad][128] = value - 128 (values are integers 0..255), device
+    int* norm;        // int32 [n_pad] squared L2 norms of the SHIFTED rows (the kNN works on differences only), device
+    int* tneg;        // int32 [n_pad] = -norm: the MFMA accumulator starts at tneg >> 1; norm + n_pad
     int* flag;        // device int: 1 if some value was not an integer in 0..255
     int integral;     // host copy of !flag, valid after creation
     // sets produced by imatch_sift_extract also carry:

@@ -1,27 +1,36 @@
-// Brute-force kNN (k = 2) on bf16 MFMA with the top-2 selection fused into the epilogue.
+// Brute-force kNN (k = 2) on int8 MFMA with the top-2 selection fused into the epilogue.
 // Replaces cv2.BFMatcher(NORM_L2).knnMatch(k=2) and the ratio loop of
 // match_finder.find_matches (reference match_finder.py:177-197).
 //
-// Formulation: ssd(q,t) = |q|^2 + |t|^2 - 2 q.t. For integer descriptors 0..255 every product
-// and every 128-term sum is an integer below 2^24, so the bf16 MFMA with f32 accumulate is
-// exact, and so is v = |t|^2 - 2 q.t computed with one f32 fma. |q|^2 is added in the merge.
+// Formulation: SIFT descriptors are integers 0..255. A row is stored as x' = x - 128 (int8), which leaves every
+// difference, so every distance, as it was: ssd(q,t) = |q'|^2 + |t'|^2 - 2 q'.t'. v_mfma_i32_16x16x64_i8 forms q'.t' in
+// exact 32-bit integer arithmetic at twice the multiply-adds per clock of the bf16 instruction (MI355X_MICROARCH.md,
+// matrix cores: "the cycles of the BF16 form of the same MxN at 2x the K"): two instructions per 16x16 block of 128-d
+// rows instead of four, half the bytes per row in HBM, L2 and LDS, half the registers for the resident queries. (Rounds
+// 1 and 2 ran this kernel on bf16 operands, which are also exact for these values; git history has that form.)
 //
-// Tiling (wave64, v_mfma_f32_32x32x16_bf16): the TRAIN rows are the A operand (rows of the
-// 32x32 result sit in the 16 accumulator registers), the QUERIES are the B operand (columns
-// sit on the lanes). Each lane therefore owns one query per 32-query block and can keep that
-// query's running top-2 in its own registers. A wave holds the B fragments of 32*QB queries
-// in registers for the whole kernel; train rows stream HBM -> LDS (global_load_lds, 16 B per
+// Tiling (wave64): the TRAIN rows are the A operand (a lane sees rows 4*(lane >> 4) .. +3 of a 16-row tile in its four
+// accumulator registers), the QUERIES are the B operand (query lane & 15 of a 16-query block sits on the lane), so a
+// query's running top-2 is kept by four lanes in REGISTERS (four partial lists per train chunk, merged at the end). A wave
+// holds the fragments of 16*QB queries for the whole kernel; train rows stream HBM -> LDS (global_load_lds, 16 B per
 // lane, XOR-swizzled through the source address) and are read as A fragments by ds_read_b128.
-// The epilogue costs one fma and one compare per result: only results below the query's
-// current second-best take the (wave-uniform, rare) insertion path.
+//
+// Per block the accumulator starts at C = T' >> 1 with T' = -|t'|^2 of the result row (i.e. -ceil(|t'|^2 / 2)), so the chain
+// ends with acc = q'.t' + (T' >> 1) and the exact partial distance is x = |t'|^2 - 2 q'.t' = -2 acc - (T' & 1). A result can
+// enter the query's top-2 only if x <= T, T = an upper bound of the query's final second-best; whatever the parity bit,
+// that needs acc >= G = -((T + 1) >> 1): the hot epilogue is a 4-way max and ONE compare per block; the insertion path
+// (wave-uniform, rare) recomputes x exactly with the parity bit re-read from LDS. T is shared chip-wide: waves publish
+// their bounds with atomicMin into gthr once per exchange and fetch the minimum back (asynchronously, into LDS), so short
+// train chunks do not keep loose bounds. The chain of block u+1 is issued before the epilogue of block u (two accumulator
+// sets), so the VALU work hides under the MFMAs.
+//
+// Pad rows (index >= n) are zero bytes with T' = -2^24: their x = 2^24 lies above every real value (< 2^23), so a pad only
+// ever sits in a slot that no real row has claimed, and the merge drops entries whose index is not below n.
 #include "common.h"
 #include <float.h>
 #include <limits.h>
 #include <math.h>
 #include <mutex>
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -62,253 +71,13 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(LDS_AS const char*)p);
 }
 
-// float <-> int with the same ordering (negative floats included), for atomicMin on thresholds
-__device__ __forceinline__ int ord_i(float f) { const int i = __float_as_int(f); return i ^ ((i >> 31) & 0x7fffffff); }
-__device__ __forceinline__ float ord_f(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
+typedef int __attribute__((ext_vector_type(4))) i32x4;
 
-__device__ __forceinline__ float max16(const f32x16& a) {
-    const float m0 = fmaxf(fmaxf(a[0], a[1]), a[2]), m1 = fmaxf(fmaxf(a[3], a[4]), a[5]);
-    const float m2 = fmaxf(fmaxf(a[6], a[7]), a[8]), m3 = fmaxf(fmaxf(a[9], a[10]), a[11]);
-    const float m4 = fmaxf(fmaxf(a[12], a[13]), a[14]);
-    return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), a[15]));
-}
+#define KNN_INF 0x7f7f7f7f            // "no bound yet" / an empty list slot (what hipMemset 0x7f leaves in a word)
+#define KNN_PAD_TNEG (-(1 << 24))     // T' of a pad row
 
-// QB 32-query blocks per wave (4 waves: 128*QB queries per workgroup), TN train rows per LDS stage.
-//
-// Per 32x32 block the accumulator starts at C = -|t|^2/2 (per result row), so the MFMA chain ends
-// with acc = q.t - |t|^2/2 = -v/2 where v = |t|^2 - 2 q.t (exact: every partial sum is a multiple of
-// 1/2 below 2^23). A result can enter the query's top-2 only if v <= T, T = an upper bound of the
-// query's final second-best, i.e. acc >= G = -T/2: the hot epilogue is a 16-way max (v_max3 tree) and
-// ONE compare per block; the insertion path is wave-uniform and rare: it fetches the query's running
-// top-2 from LDS, folds the block's 16 accumulator registers into it with branch-free selects and puts
-// it back, so the hot loop carries only G in registers. T is shared chip-wide: every wave publishes its second-best with
-// atomicMin into gthr[query] once per stage and fetches the minimum back (asynchronously, into LDS),
-// so short train chunks do not keep loose thresholds. The chain of block u+1 is issued before the
-// epilogue of block u (two accumulator sets), so the VALU work hides under the MFMAs.
-// The whole kernel stays below 256 VGPRs: the MFMAs then keep their accumulators in VGPRs, which the
-// VALU reads directly, and two workgroups share a CU.
-template <int QB, int TN>
-__global__ void __launch_bounds__(256, 2)
-knn2_kernel(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ thneg,
-            int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi,
-            int* __restrict__ gthr, int stage0, int list0, int rot) {
-    constexpr int STAGE_U4 = TN * 16 + TN / 4;   // uint4 per stage: TN rows x 256 B, then TN f32 (-|t|^2/2)
-    constexpr int NT = TN / 32;                  // 32-row tiles per stage
-    constexpr int ST_F = QB * 256;               // floats of top-2 state per wave: [QB][b1,b2,i1,i2][64]
-    constexpr int TH_F = 3 * QB * 64;            // floats of fetched thresholds per wave: [3][QB][64]
-    __shared__ uint4 lds[2 * STAGE_U4 + (4 * ST_F + 4 * TH_F) / 4];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    float* const extra = (float*)(lds + 2 * STAGE_U4);
-    float* const st = extra + wave * ST_F;
-    float* const thl = extra + 4 * ST_F + wave * TH_F;
-
-    // workgroups b and b+8 share an XCD (its L2): same train chunk, different query tiles
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int chunk = (j / nQt) * 8 + xcd;
-    if (chunk >= nChunks) return;
-    // Every XCD walks the query tiles from a different start: a tile then meets its chunks one XCD after the other
-    // instead of on all eight at once, so only its FIRST chunk is scanned with loose bounds -- the others inherit the
-    // chip-wide words.
-    const int qt = (j % nQt + (rot ? (xcd * nQt) >> 3 : 0)) % nQt;
-    const int s_begin = stage0 + (int)((int64_t)nStages * chunk / nChunks);
-    const int s_end = stage0 + (int)((int64_t)nStages * (chunk + 1) / nChunks);
-
-    // resident query fragments: lane holds q[row r][k = 16 ks + 8 h .. +7] = 16-byte chunk 2 ks + h
-    const int64_t qrow0 = (int64_t)qt * (4 * 32 * QB) + wave * (32 * QB);
-    bf16x8 qf[QB][8];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            uint4 u = Qd[(qrow0 + qb * 32 + r) * 16 + 2 * ks + h];
-            qf[qb][ks] = __builtin_bit_cast(bf16x8, u);
-        }
-
-    const int* gq = gthr + qrow0;                 // wave-uniform base of this wave's thresholds
-    float G[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        st[qb * 256 + lane] = FLT_MAX; st[qb * 256 + 64 + lane] = FLT_MAX;
-        st[qb * 256 + 128 + lane] = __int_as_float(-1); st[qb * 256 + 192 + lane] = __int_as_float(-1);
-        const int t0 = __hip_atomic_load(gq + qb * 32 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        thl[qb * 64 + lane] = __int_as_float(t0);
-        thl[(QB + qb) * 64 + lane] = __int_as_float(0x7f7f7f7f);
-        thl[(2 * QB + qb) * 64 + lane] = __int_as_float(0x7f7f7f7f);
-        G[qb] = -0.5f * ord_f(t0);
-    }
-
-    // Stage loader. The LDS image is lane-linear; the swizzle chunk' = chunk ^ (row & 15) is applied to
-    // the per-lane SOURCE address. slot = i*256 + wave*64 + lane -> row = i*16 + (wave*4 + lane/16), so
-    // every piece is (uniform base) + (one per-lane byte offset that never changes).
-    const unsigned lds0 = lds_addr_of(lds);
-    auto stage = [&](int s, int buf) {
-        const unsigned ln = lane_now();
-        const unsigned r0 = (unsigned)wave * 4u + (ln >> 4);
-        const unsigned lane_off = (r0 * 16 + ((ln & 15) ^ (r0 & 15))) * 16;   // bytes
-        const char* src = (const char*)(Td + (int64_t)s * TN * 16);
-#pragma unroll
-        for (int i = 0; i < (TN * 16) / 256; ++i)
-            glds16(uniform_ptr(src + i * 4096), lane_off, lds0 + (buf * STAGE_U4 + i * 256 + wave * 64) * 16);
-        if (wave < TN / 64)
-            glds4(uniform_ptr(thneg + (int64_t)s * TN + wave * 64), ln * 4,
-                  lds0 + (buf * STAGE_U4 + TN * 16) * 16 + wave * 256);
-    };
-
-    // (Three stage buffers with the loads two stages ahead were tried: no change at any shape, so the waves do not
-    // wait for the DMA; rocprofv3 puts 30 % of the wave cycles in waits, 41 % in issue stalls behind the shared MFMA pipe.)
-    if (s_begin < s_end) stage(s_begin, 0);
-    for (int s = s_begin; s < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // Thresholds fetched during the previous exchange -> G; publish this wave's second-best only when
-        // it lowers the chip-wide value. Exchanges happen at every stage while a chunk is young (that
-        // is when bounds move), then at every fourth stage.
-        const int age = s - s_begin;
-        const bool exchange = age < 8 || (age & 3) == 0;
-        if (exchange) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                // Chip-wide bound on the query's second-best: the least second-best any list holds, or the
-                // larger of the two least BESTS of the h = 0 and h = 1 lists (disjoint rows, so two rows lie
-                // below it). The second form matters: the two nearest rows rarely sit in the same list, and
-                // min-of-second-bests alone left the bound at about the 13th nearest of what the chip had seen.
-                const float tg = ord_f(__float_as_int(thl[qb * 64 + lane]));
-                const float ta = ord_f(__float_as_int(thl[(QB + qb) * 64 + lane]));
-                const float tb = ord_f(__float_as_int(thl[(2 * QB + qb) * 64 + lane]));
-                G[qb] = fmaxf(G[qb], -0.5f * fminf(tg, fmaxf(ta, tb)));
-                const float b1 = st[qb * 256 + lane], b2 = st[qb * 256 + 64 + lane];
-                if (b2 < tg) atomicMin(const_cast<int*>(gq) + qb * 32 + r, ord_i(b2));
-                if (b1 < (h ? tb : ta)) atomicMin(const_cast<int*>(gq) + (1 + h) * Qpad + qb * 32 + r, ord_i(b1));
-            }
-        }
-        // asynchronous loads: next stage, and the chip-wide thresholds for the next exchange (sc1: from memory)
-        if (s + 1 < s_end) stage(s + 1, buf ^ 1);
-        if (exchange) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    glds4_sc1(uniform_ptr(gq + a * Qpad + qb * 32), (lane_now() & 31) * 4,
-                              lds_addr_of(thl) + (a * QB + qb) * 256);
-        }
-        const unsigned lf = lane_now();
-        const unsigned frag_off = (lf & 31) * 256u + ((((lf >> 5) ^ lf) & 15) << 4);
-
-        const uint4* img = lds + buf * STAGE_U4;
-        bf16x8 af[8];
-        f32x16 hneg;
-        // chunk (2ks+h)^(r&15) = ((h^r)&15) ^ 2ks and the row's byte offset has its low 8 bits clear, so
-        // all eight fragment addresses of a tile are ONE per-lane address XOR an immediate
-        auto load_tile = [&](int tile) {
-            const unsigned a0 = (unsigned)tile * 8192u + frag_off;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                uint4 u = *(const uint4*)((const char*)img + (a0 ^ (unsigned)(ks << 5)));
-                af[ks] = __builtin_bit_cast(bf16x8, u);
-            }
-            // -|t|^2/2 of the 16 train rows this lane sees: row(reg) = (reg&3) + 8*(reg>>2) + 4*h
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint4 u = img[TN * 16 + tile * 8 + 2 * g + h];
-                hneg[4 * g + 0] = __uint_as_float(u.x);
-                hneg[4 * g + 1] = __uint_as_float(u.y);
-                hneg[4 * g + 2] = __uint_as_float(u.z);
-                hneg[4 * g + 3] = __uint_as_float(u.w);
-            }
-        };
-        auto chain = [&](int qb) {
-            f32x16 acc = hneg;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], qf[qb][ks], acc, 0, 0, 0);
-            return acc;
-        };
-        // Insertion path (rare, wave-uniform entry). Rows are visited in ascending train index with
-        // strict <: OpenCV's lowest-index tie-break.
-        auto epilogue = [&](const f32x16& a, int qb, int tile) {
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(max16(a) >= G[qb]) != 0, 0)) {   // rare: hot path = fall-through
-                float* sq = st + qb * 256;
-                float b1 = sq[lane], b2 = sq[64 + lane];
-                int i1 = __float_as_int(sq[128 + lane]), i2 = __float_as_int(sq[192 + lane]);
-                // (the empty asm pins the row numbers to this path: the compiler otherwise computes all sixteen of them
-                // before the branch, on every block, which was 40 % of the hot path's vector instructions)
-                int rowbase = s * TN + tile * 32 + 4 * h;
-                asm volatile("" : "+v"(rowbase));
-                const float g = G[qb];
-                // all 16 results straight from the accumulator registers, branch-free selects
-                // (a register none of whose 64 results passes the bound is skipped with one compare and a scalar
-                // branch: usually one or two of the sixteen have a candidate)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float v = a[reg];
-                    const bool pass = v >= g;
-                    if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
-                    const float x = -2.0f * v;
-                    const int idx = rowbase + (reg & 3) + 8 * (reg >> 2);
-                    const bool lt1 = pass && x < b1;
-                    const bool lt2 = pass && !lt1 && x < b2;
-                    b2 = lt1 ? b1 : (lt2 ? x : b2);
-                    i2 = lt1 ? i1 : (lt2 ? idx : i2);
-                    b1 = lt1 ? x : b1;
-                    i1 = lt1 ? idx : i1;
-                }
-                sq[lane] = b1; sq[64 + lane] = b2;
-                sq[128 + lane] = __int_as_float(i1); sq[192 + lane] = __int_as_float(i2);
-                G[qb] = fmaxf(g, -0.5f * b2);
-            }
-        };
-
-        load_tile(0);
-        f32x16 acc0 = chain(0), acc1;
-        if constexpr (QB == 1) {
-            // one block per tile: no chain to hide the epilogue under
-#pragma unroll 1
-            for (int tile = 0; tile < NT; ++tile) {
-                const f32x16 a = acc0;
-                if (tile + 1 < NT) {
-                    load_tile(tile + 1);
-                    acc0 = chain(0);
-                }
-                epilogue(a, 0, tile);
-            }
-        } else {
-#pragma unroll 1
-            for (int tile = 0; tile < NT; ++tile) {
-#pragma unroll
-                for (int qb = 0; qb < QB; qb += 2) {
-                    // block qb+1 of this tile is issued, then block qb is examined
-                    acc1 = chain(qb + 1);
-                    if (qb == QB - 2 && tile + 1 < NT) load_tile(tile + 1);  // the tile's last chain is out
-                    epilogue(acc0, qb, tile);
-                    if (qb + 2 < QB) acc0 = chain(qb + 2);
-                    else if (tile + 1 < NT) acc0 = chain(0);                  // first block of the next tile
-                    epilogue(acc1, qb + 1, tile);
-                }
-            }
-        }
-    }
-
-    // one partial list per (chunk, lane half)
-    const int64_t list = (int64_t)(list0 + chunk) * 2 + h;
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int64_t o = list * Qpad + qrow0 + qb * 32 + r;
-        pb[o] = make_float2(st[qb * 256 + lane], st[qb * 256 + 64 + lane]);
-        pi[o] = make_int2(__float_as_int(st[qb * 256 + 128 + lane]), __float_as_int(st[qb * 256 + 192 + lane]));
-    }
-}
-
-// ---- the same kernel on v_mfma_f32_16x16x32_bf16 ---------------------------------------------------
-// Same operand roles (train rows = A, queries = B), same LDS image and stage loader, same bound exchange. A lane owns
-// query (lane & 15) of a 16-query block and sees rows 4*(lane >> 4) .. +3 of a 16-row tile, so a query's running top-2 is
-// kept by four lanes (four partial lists per train chunk) -- in REGISTERS here: with 4 accumulator registers per block
-// instead of 16 there is room for them, and the insertion path touches no LDS. Per MI355X_MICROARCH.md a 16x16x32 loop
-// delivers about 1.15x the FLOP/s of a 32x32x16 loop at equal cycles per FLOP (it draws less power; this kernel ran at
-// 2.09 GHz by GRBM_GUI_ACTIVE), which is the reason for this variant.
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+// acc >= bound_g(T) is necessary for x = -2 acc - parity <= T
+__device__ __forceinline__ int bound_g(int T) { return -((T + 1) >> 1); }
 
 #ifdef KNN_TRACE   // development only (tools/dbg/knn_trace.py): per-workgroup wall-clock stamps (100 MHz)
 #define KNN_TRACE_SLOTS 40
@@ -322,111 +91,121 @@ extern "C" int imatch_dbg_knn_trace(long long* out) {
 #define KT(slot) do {} while (0)
 #endif
 
+// QB blocks of 16 queries per wave (8: 128 queries, 512 per workgroup; 4: 256 per workgroup), TN train rows per LDS stage,
+// XM + 1 stages between bound exchanges once a chunk is no longer young.
 // SHORT: the 512-query form for a few query tiles against chunks of a few dozen stages (a frame against a large map):
 // the 256-query form's first exchange (merged publishing, waited for) without its key registers.
-template <int QB, int TN, int XM, bool SHORT = false>   // QB blocks of 16 queries per wave (8: 128 queries, 512 per workgroup as above)
+template <int QB, int TN, int XM, bool SHORT = false>
 __global__ void __launch_bounds__(256, 2)
-knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const float* __restrict__ thneg,
-              int nQt, int nChunks, int nStages, int64_t Qpad, float2* __restrict__ pb, int2* __restrict__ pi,
-              int* __restrict__ gthr, int young, unsigned young_wg, int stage0, int list0, int rot) {
-    static_assert(QB % 4 == 0, "thresholds are fetched 64 queries at a time");
-    static_assert(TN <= 128, "the first-stage keys hold a 7-bit row");
-    // the key form of a young chunk's first stage (below) costs 2 * QB registers: only the 256-query form has them to
-    // spare (the 512-query form would spill), and it is the one whose chunks are short enough for the first stage to matter
+knn2_kernel8(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const int* __restrict__ tneg,
+             int nQt, int nChunks, int nStages, int64_t Qpad, int2* __restrict__ pb, int2* __restrict__ pi,
+             int* __restrict__ gthr, int young, unsigned young_wg, int stage0, int list0, int rot) {
+    static_assert(QB % 4 == 0, "bounds are fetched 64 queries at a time");
+    static_assert(TN <= 128 || QB > 4, "the first-stage keys hold a 7-bit row");
+    static_assert(TN % 64 == 0, "the T' words of a stage are loaded 64 at a time");
+    // the key form of a young chunk's first stage (below) costs 2 * QB registers and is worth them where chunks are short
     constexpr bool KEY0 = QB <= 4;
     constexpr bool MERGED = KEY0 || SHORT;   // lane-merged publishing; the second stage waits for the first exchange
-    constexpr int STAGE_U4 = TN * 16 + TN / 4;
+    constexpr int STAGE_U4 = TN * 8 + TN / 4;    // uint4 per stage: TN rows x 128 B, then TN int32 (T' = -|t'|^2)
     constexpr int NT = TN / 16;                  // 16-row tiles per stage
-    constexpr int TH_F = 3 * (QB / 4) * 64;      // fetched thresholds per wave: [3][QB/4][64 queries]
+    constexpr int TH_F = 3 * (QB / 4) * 64;      // fetched bound words per wave: [3][QB/4][64 queries]
     __shared__ uint4 lds[2 * STAGE_U4 + (4 * TH_F) / 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4, grp = q >> 1;
-    float* const thl = (float*)(lds + 2 * STAGE_U4) + wave * TH_F;
+    int* const thl = (int*)(lds + 2 * STAGE_U4) + wave * TH_F;
 
+    // workgroups b and b+8 share an XCD (its L2): same train chunk, different query tiles
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int chunk = (j / nQt) * 8 + xcd;
     KT(0);
     if (chunk >= nChunks) return;
-    const int qt = (j % nQt + (rot ? (xcd * nQt) >> 3 : 0)) % nQt;   // see knn2_kernel
+    // Every XCD walks the query tiles from a different start: a tile then meets its chunks one XCD after the other
+    // instead of on all eight at once, so only its FIRST chunk is scanned with loose bounds -- the others inherit the
+    // chip-wide words.
+    const int qt = (j % nQt + (rot ? (xcd * nQt) >> 3 : 0)) % nQt;
     const int s_begin = stage0 + (int)((int64_t)nStages * chunk / nChunks);
     const int s_end = stage0 + (int)((int64_t)nStages * (chunk + 1) / nChunks);
 
-    // resident query fragments: lane holds q[row r of block qb][k = 32 t + 8 q .. +7] = 16-byte chunk 4 t + q
+    // resident query fragments: lane holds bytes 16 (4 t + q) .. +15 of row r of block qb (k-step t = 0, 1). The train
+    // fragment below takes the SAME bytes of its row on the same lane, so the sum over k pairs equal dimensions whatever
+    // order the instruction walks a lane's sixteen bytes in.
     const int64_t qrow0 = (int64_t)qt * (4 * 16 * QB) + wave * (16 * QB);
-    bf16x8 qf[QB][4];
+    i32x4 qf[QB][2];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            uint4 u = Qd[(qrow0 + qb * 16 + r) * 16 + 4 * t + q];
-            qf[qb][t] = __builtin_bit_cast(bf16x8, u);
+        for (int t = 0; t < 2; ++t) {
+            uint4 u = Qd[(qrow0 + qb * 16 + r) * 8 + 4 * t + q];
+            qf[qb][t] = __builtin_bit_cast(i32x4, u);
         }
 
-    const int* gq = gthr + qrow0;                 // wave-uniform base of this wave's thresholds
-    float G[QB], b1[QB], b2[QB];
+    const int* gq = gthr + qrow0;                 // wave-uniform base of this wave's bound words
+    int G[QB], b1[QB], b2[QB];
     int i1[QB], i2[QB];
-    // fetched thresholds of block qb, word a: thl[(a * (QB/4) + (qb >> 2)) * 64 + (qb & 3) * 16 + r]
+    // fetched bounds of block qb, word a: thl[(a * (QB/4) + (qb >> 2)) * 64 + (qb & 3) * 16 + r]
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        b1[qb] = FLT_MAX; b2[qb] = FLT_MAX; i1[qb] = -1; i2[qb] = -1;
+        b1[qb] = KNN_INF; b2[qb] = KNN_INF; i1[qb] = -1; i2[qb] = -1;
         const int t0 = __hip_atomic_load(gq + qb * 16 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int at = (qb >> 2) * 64 + (qb & 3) * 16 + r;
-        thl[at] = __int_as_float(t0);
-        thl[(QB / 4) * 64 + at] = __int_as_float(0x7f7f7f7f);
-        thl[2 * (QB / 4) * 64 + at] = __int_as_float(0x7f7f7f7f);
-        G[qb] = -0.5f * ord_f(t0);
+        thl[at] = t0;
+        thl[(QB / 4) * 64 + at] = KNN_INF;
+        thl[2 * (QB / 4) * 64 + at] = KNN_INF;
+        G[qb] = bound_g(t0);
     }
 
+    // Stage loader. The LDS image is lane-linear (a wave's piece = 1 KiB = 8 rows of 8 chunks); the swizzle
+    // chunk' = chunk ^ (row & 7) is applied to the per-lane SOURCE address. slot = i*256 + wave*64 + lane ->
+    // row = i*32 + wave*8 + lane/8, so every piece is (uniform base) + (one per-lane byte offset that never changes).
     const unsigned lds0 = lds_addr_of(lds);
     auto stage = [&](int s, int buf) {
         const unsigned ln = lane_now();
-        const unsigned r0 = (unsigned)wave * 4u + (ln >> 4);
-        const unsigned lane_off = (r0 * 16 + ((ln & 15) ^ (r0 & 15))) * 16;   // bytes
-        const char* src = (const char*)(Td + (int64_t)s * TN * 16);
+        const unsigned r0 = (unsigned)wave * 8u + (ln >> 3);
+        const unsigned lane_off = (r0 * 8 + ((ln & 7) ^ (r0 & 7))) * 16;   // bytes
+        const char* src = (const char*)(Td + (int64_t)s * TN * 8);
 #pragma unroll
-        for (int i = 0; i < (TN * 16) / 256; ++i)
+        for (int i = 0; i < (TN * 8) / 256; ++i)
             glds16(uniform_ptr(src + i * 4096), lane_off, lds0 + (buf * STAGE_U4 + i * 256 + wave * 64) * 16);
         if (wave < TN / 64)
-            glds4(uniform_ptr(thneg + (int64_t)s * TN + wave * 64), ln * 4,
-                  lds0 + (buf * STAGE_U4 + TN * 16) * 16 + wave * 256);
+            glds4(uniform_ptr(tneg + (int64_t)s * TN + wave * 64), ln * 4,
+                  lds0 + (buf * STAGE_U4 + TN * 8) * 16 + wave * 256);
     };
 
-    // Bound exchange. take: fold the fetched chip-wide words into G. publish: the wave's own bounds -- in the 256-query
-    // form (KEY0: short chunks, a frame against a map) merged over the four lanes that share a query first, one atomic per
+    // Bound exchange. take: fold the fetched chip-wide words into G. publish: the wave's own bounds -- in the MERGED
+    // forms (short chunks, a frame against a map) merged over the four lanes that share a query first, one atomic per
     // word, query and wave instead of four: at a chunk's first exchange every lane has something to say, and forty
     // workgroups per query tile say it to the same addresses (11.6 us -> 1.4 us for that exchange at 1500 x 59k).
     auto take_bounds = [&]() {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const int at = (qb >> 2) * 64 + (qb & 3) * 16 + r;
-            const float tg = ord_f(__float_as_int(thl[at]));
-            const float ta = ord_f(__float_as_int(thl[(QB / 4) * 64 + at]));
-            const float tb = ord_f(__float_as_int(thl[2 * (QB / 4) * 64 + at]));
-            // rows of lists q = 0,1 and of lists q = 2,3 are disjoint: the larger of the two groups' least bests
-            // bounds the second-best, as does the least second-best of any list
-            G[qb] = fmaxf(G[qb], -0.5f * fminf(tg, fmaxf(ta, tb)));
+            const int tg = thl[at], ta = thl[(QB / 4) * 64 + at], tb = thl[2 * (QB / 4) * 64 + at];
+            // Chip-wide bound on the query's second-best: the least second-best any list holds, or -- rows of lists
+            // q = 0,1 and of lists q = 2,3 are disjoint -- the larger of the two groups' least BESTS (two rows lie below
+            // it). The second form matters: the two nearest rows rarely sit in the same list.
+            G[qb] = max(G[qb], bound_g(min(tg, max(ta, tb))));
         }
     };
     auto publish_bounds = [&]() {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const int at = (qb >> 2) * 64 + (qb & 3) * 16 + r;
-            const float tg = ord_f(__float_as_int(thl[at]));
-            const float tgrp = ord_f(__float_as_int(thl[(1 + grp) * (QB / 4) * 64 + at]));
+            const int tg = thl[at];
+            const int tgrp = thl[(1 + grp) * (QB / 4) * 64 + at];
             if (MERGED) {
-                float m2 = fminf(b2[qb], __shfl_xor(b2[qb], 16));
-                m2 = fminf(m2, __shfl_xor(m2, 32));                        // least second-best of the four lists
-                const float m1 = fminf(b1[qb], __shfl_xor(b1[qb], 16));   // least best of the group's two lists
-                if (q == 0 && m2 < tg) atomicMin(const_cast<int*>(gq) + qb * 16 + r, ord_i(m2));
-                if ((q & 1) == 0 && m1 < tgrp) atomicMin(const_cast<int*>(gq) + (1 + grp) * Qpad + qb * 16 + r, ord_i(m1));
+                int m2 = min(b2[qb], __shfl_xor(b2[qb], 16));
+                m2 = min(m2, __shfl_xor(m2, 32));                        // least second-best of the four lists
+                const int m1 = min(b1[qb], __shfl_xor(b1[qb], 16));     // least best of the group's two lists
+                if (q == 0 && m2 < tg) atomicMin(const_cast<int*>(gq) + qb * 16 + r, m2);
+                if ((q & 1) == 0 && m1 < tgrp) atomicMin(const_cast<int*>(gq) + (1 + grp) * Qpad + qb * 16 + r, m1);
             } else {   // long chunks exchange rarely and have little to say: every lane for itself, no shuffles
-                if (b2[qb] < tg) atomicMin(const_cast<int*>(gq) + qb * 16 + r, ord_i(b2[qb]));
-                if (b1[qb] < tgrp) atomicMin(const_cast<int*>(gq) + (1 + grp) * Qpad + qb * 16 + r, ord_i(b1[qb]));
+                if (b2[qb] < tg) atomicMin(const_cast<int*>(gq) + qb * 16 + r, b2[qb]);
+                if (b1[qb] < tgrp) atomicMin(const_cast<int*>(gq) + (1 + grp) * Qpad + qb * 16 + r, b1[qb]);
             }
         }
     };
-    auto fetch_bounds = [&]() {
+    auto fetch_bounds = [&]() {   // sc1: from memory, not from this CU's or XCD's caches
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -456,44 +235,48 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
             take_bounds();
             publish_bounds();
         }
+        // asynchronous loads: the next stage, and the chip-wide words for the next exchange
         if (s + 1 < s_end) stage(s + 1, buf ^ 1);
         if (exchange) fetch_bounds();
         const unsigned lf = lane_now();
-        const unsigned frag_off = (lf & 15) * 256u + ((((lf >> 4) ^ lf) & 15) << 4);
+        const unsigned frag_off = (lf & 15) * 128u + ((((lf >> 4) ^ lf) & 7) << 4);
         const uint4* img = lds + buf * STAGE_U4;
-        bf16x8 af[4];
-        f32x4 hneg;
-        // chunk (4t + q) ^ (r & 15) = ((q ^ r) & 15) ^ 4t: one per-lane address XOR an immediate per k-step
+        i32x4 af[2], tin, traw;
+        // chunk (4t + q) ^ (r & 7) = ((q ^ r) & 7) ^ 4t: one per-lane address XOR an immediate per k-step
         auto load_tile = [&](int tile) {
-            const unsigned a0 = (unsigned)tile * 4096u + frag_off;
+            const unsigned a0 = (unsigned)tile * 2048u + frag_off;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 2; ++t) {
                 uint4 u = *(const uint4*)((const char*)img + (a0 ^ (unsigned)(t << 6)));
-                af[t] = __builtin_bit_cast(bf16x8, u);
+                af[t] = __builtin_bit_cast(i32x4, u);
             }
-            const uint4 u = img[TN * 16 + tile * 4 + (int)(lf >> 4)];   // -|t|^2/2 of rows 4q .. 4q+3 of the tile
-            hneg[0] = __uint_as_float(u.x); hneg[1] = __uint_as_float(u.y);
-            hneg[2] = __uint_as_float(u.z); hneg[3] = __uint_as_float(u.w);
+            const uint4 u = img[TN * 8 + tile * 4 + (int)(lf >> 4)];   // T' of rows 4q .. 4q+3 of the tile
+            traw = __builtin_bit_cast(i32x4, u);
+            tin = traw >> 1;
         };
         auto chain = [&](int qb) {
-            f32x4 acc = hneg;
+            i32x4 acc = tin;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], qf[qb][t], acc, 0, 0, 0);
+            for (int t = 0; t < 2; ++t)
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[t], qf[qb][t], acc, 0, 0, 0);
             return acc;
         };
-        auto epilogue = [&](const f32x4& a, int qb, int tile) {
-            const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+        // Insertion path (rare, wave-uniform entry). Rows are visited in ascending train index with strict <: OpenCV's
+        // lowest-index tie-break.
+        auto epilogue = [&](const i32x4& a, int qb, int tile) {
+            const int m = max(max(a[0], a[1]), max(a[2], a[3]));
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= G[qb]) != 0, 0)) {   // rare: keep the hot path the fall-through
                 int rowbase = s * TN + tile * 16 + 4 * q;
                 asm volatile("" : "+v"(rowbase));
-                const float g = G[qb];
+                const uint4 tw = img[TN * 8 + tile * 4 + q];   // the rows' parity bits (the tile's T' words again)
+                const int par[4] = {(int)(tw.x & 1u), (int)(tw.y & 1u), (int)(tw.z & 1u), (int)(tw.w & 1u)};
+                const int g = G[qb];
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {   // ascending train index, strict <: the lowest index wins ties
-                    const float v = a[reg];
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int v = a[reg];
                     const bool pass = v >= g;
                     if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
-                    const float x = -2.0f * v;
+                    const int x = -2 * v - par[reg];
                     const int idx = rowbase + reg;
                     const bool lt1 = pass && x < b1[qb];
                     const bool lt2 = pass && !lt1 && x < b2[qb];
@@ -502,28 +285,28 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
                     b1[qb] = lt1 ? x : b1[qb];
                     i1[qb] = lt1 ? idx : i1[qb];
                 }
-                G[qb] = fmaxf(g, -0.5f * b2[qb]);
+                G[qb] = max(g, bound_g(b2[qb]));
             }
         };
 
         KT(5 + 2 * (s - s_begin));
         load_tile(0);
-        f32x4 acc0 = chain(0), acc1;
+        i32x4 acc0 = chain(0), acc1;
         if (KEY0 && age == 0 && young_now) {
             // A young chunk's FIRST stage has no bound to test against: nearly every block would take the insertion path
-            // (60 vector instructions). Its results go through a branch-free top-2 of 32-bit KEYS instead -- value
-            // + 2^23 (an exact integer below 2^24) above the row's 7-bit place in the stage, so key order is (value, row)
-            // order, lowest row first on ties -- 5 instructions per result; the lists are empty before this stage, so its
-            // two best keys simply become them. A pad row's +inf converts to a key above 2^31: never taken.
+            // (60 vector instructions). Its results go through a branch-free top-2 of 32-bit KEYS instead -- x + 2^23
+            // (below 2^24 for a real row) above the row's 7-bit place in the stage, so key order is (value, row) order,
+            // lowest row first on ties -- a handful of instructions per result; the lists are empty before this stage, so
+            // its two best keys simply become them. A pad row's x = 2^24 gives a key of 2^31 or more: never taken.
             unsigned k1[QB], k2[QB];
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) { k1[qb] = 0xffffffffu; k2[qb] = 0xffffffffu; }
-            auto epilogue_key = [&](const f32x4& a, int qb, int tile) {
+            i32x4 pc;   // 2^23 - parity of the CURRENT tile's rows (load_tile(tile + 1) runs before the tile's last epilogues)
+            auto epilogue_key = [&](const i32x4& a, int qb, int tile) {
                 const unsigned rowl = (unsigned)tile * 16u + 4u * (unsigned)q;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    unsigned u;   // saturating conversion: +inf -> 0xffffffff
-                    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(fmaf(-2.0f, a[reg], 8388608.0f)));
+                    const unsigned u = (unsigned)(pc[reg] - 2 * a[reg]);
                     const unsigned key = (u << 7) | (rowl + reg);
                     const unsigned t = max(k1[qb], key);
                     k1[qb] = min(k1[qb], key);
@@ -532,6 +315,7 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
             };
 #pragma unroll 1
             for (int tile = 0; tile < NT; ++tile) {
+                pc = 0x800000 - (traw & 1);
 #pragma unroll
                 for (int qb = 0; qb < QB; qb += 2) {
                     acc1 = chain(qb + 1);
@@ -544,40 +328,41 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
             }
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                if (k1[qb] < 0x80000000u) { b1[qb] = (float)(k1[qb] >> 7) - 8388608.0f; i1[qb] = s * TN + (int)(k1[qb] & 127u); }
-                if (k2[qb] < 0x80000000u) { b2[qb] = (float)(k2[qb] >> 7) - 8388608.0f; i2[qb] = s * TN + (int)(k2[qb] & 127u); }
-                G[qb] = fmaxf(G[qb], -0.5f * b2[qb]);
+                if (k1[qb] < 0x80000000u) { b1[qb] = (int)(k1[qb] >> 7) - 0x800000; i1[qb] = s * TN + (int)(k1[qb] & 127u); }
+                if (k2[qb] < 0x80000000u) { b2[qb] = (int)(k2[qb] >> 7) - 0x800000; i2[qb] = s * TN + (int)(k2[qb] & 127u); }
+                G[qb] = max(G[qb], bound_g(b2[qb]));
             }
         } else {
 #pragma unroll 1
-        for (int tile = 0; tile < NT; ++tile) {
+            for (int tile = 0; tile < NT; ++tile) {
 #pragma unroll
-            for (int qb = 0; qb < QB; qb += 2) {
-                acc1 = chain(qb + 1);
-                if (qb == QB - 2 && tile + 1 < NT) load_tile(tile + 1);
-                epilogue(acc0, qb, tile);
-                if (qb + 2 < QB) acc0 = chain(qb + 2);
-                else if (tile + 1 < NT) acc0 = chain(0);
-                epilogue(acc1, qb + 1, tile);
+                for (int qb = 0; qb < QB; qb += 2) {
+                    // block qb+1 of this tile is issued, then block qb is examined
+                    acc1 = chain(qb + 1);
+                    if (qb == QB - 2 && tile + 1 < NT) load_tile(tile + 1);  // the tile's last chain is out
+                    epilogue(acc0, qb, tile);
+                    if (qb + 2 < QB) acc0 = chain(qb + 2);
+                    else if (tile + 1 < NT) acc0 = chain(0);                  // first block of the next tile
+                    epilogue(acc1, qb + 1, tile);
+                }
             }
-        }
         }
         if (MERGED && age == 0 && young_now && young > 1) publish_bounds();   // read back, and waited for, at the top of the next stage
     }
 
     KT(2);
     // The four lanes that hold a query's lists (row quarters, disjoint rows) merge them by two exchange rounds, in
-    // (value, train index) order -- the values are exact integers, so equal values are true ties and the lower index
-    // ranks first, as the ascending scan would have it; one partial list per chunk is written.
+    // (value, train index) order -- equal values are true ties and the lower index ranks first, as the ascending scan
+    // would have it; one partial list per chunk is written.
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
-            const float ob1 = __shfl_xor(b1[qb], off), ob2 = __shfl_xor(b2[qb], off);
+            const int ob1 = __shfl_xor(b1[qb], off), ob2 = __shfl_xor(b2[qb], off);
             const int oi1 = __shfl_xor(i1[qb], off), oi2 = __shfl_xor(i2[qb], off);
             const bool o_first = ob1 < b1[qb] || (ob1 == b1[qb] && (unsigned)oi1 < (unsigned)i1[qb]);
             // the runner-up: the loser of the first comparison against the winner's own second
-            const float w1 = o_first ? ob1 : b1[qb], l1 = o_first ? b1[qb] : ob1, w2 = o_first ? ob2 : b2[qb];
+            const int w1 = o_first ? ob1 : b1[qb], l1 = o_first ? b1[qb] : ob1, w2 = o_first ? ob2 : b2[qb];
             const int wi1 = o_first ? oi1 : i1[qb], li1 = o_first ? i1[qb] : oi1, wi2 = o_first ? oi2 : i2[qb];
             const bool l_second = l1 < w2 || (l1 == w2 && (unsigned)li1 < (unsigned)wi2);
             b1[qb] = w1; i1[qb] = wi1;
@@ -588,12 +373,13 @@ knn2_kernel16(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const 
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const int64_t o = (int64_t)(list0 + chunk) * Qpad + qrow0 + qb * 16 + r;
-            pb[o] = make_float2(b1[qb], b2[qb]);
+            pb[o] = make_int2(b1[qb], b2[qb]);
             pi[o] = make_int2(i1[qb], i2[qb]);
         }
     }
     KT(3);
 }
+
 
 __device__ inline void top2_insert(int& s1, int& j1, int& s2, int& j2, int s, int j) {
     if (s < s1 || (s == s1 && j < j1)) {
@@ -603,18 +389,18 @@ __device__ inline void top2_insert(int& s1, int& j1, int& s2, int& j2, int s, in
     }
 }
 
-// merges the partial lists of one query, adds |q|^2, writes (ssd1, idx1, ssd2, idx2).
+// merges the partial lists of one query (entries of pad rows, index >= nt, dropped), adds |q'|^2, writes (ssd1, idx1, ssd2, idx2).
 // 256 threads = 16 queries x 16 list slices; the slices are combined through LDS.
 __global__ void __launch_bounds__(256)
-knn2_finish_kernel(const float2* __restrict__ pb, const int2* __restrict__ pi, int nLists, int64_t Qpad,
-                   const float* __restrict__ qnorm, int64_t nq, int64_t nt, int idx_offset, int4* __restrict__ out) {
+knn2_finish_kernel(const int2* __restrict__ pb, const int2* __restrict__ pi, int nLists, int64_t Qpad,
+                   const int* __restrict__ qnorm, int64_t nq, int64_t nt, int idx_offset, int4* __restrict__ out) {
     __shared__ int4 part[16][16];
     const int ql = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int64_t q = (int64_t)blockIdx.x * 16 + ql;
     int s1 = INT_MAX, s2 = INT_MAX, j1 = INT_MAX, j2 = INT_MAX;
     if (q < nq) {
         for (int l0 = slice; l0 < nLists; l0 += 64) {   // four lists' loads in flight (a frame's launch has 40 to 112 lists)
-            float2 b[4];
+            int2 b[4];
             int2 i[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -625,8 +411,8 @@ knn2_finish_kernel(const float2* __restrict__ pb, const int2* __restrict__ pi, i
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (l0 + 16 * u >= nLists) break;
-                if (i[u].x >= 0 && i[u].x < nt) top2_insert(s1, j1, s2, j2, (int)b[u].x, i[u].x);
-                if (i[u].y >= 0 && i[u].y < nt) top2_insert(s1, j1, s2, j2, (int)b[u].y, i[u].y);
+                if (i[u].x >= 0 && i[u].x < nt) top2_insert(s1, j1, s2, j2, b[u].x, i[u].x);
+                if (i[u].y >= 0 && i[u].y < nt) top2_insert(s1, j1, s2, j2, b[u].y, i[u].y);
             }
         }
     }
@@ -638,7 +424,7 @@ knn2_finish_kernel(const float2* __restrict__ pb, const int2* __restrict__ pi, i
         if (e.y != INT_MAX) top2_insert(s1, j1, s2, j2, e.x, e.y);
         if (e.w != INT_MAX) top2_insert(s1, j1, s2, j2, e.z, e.w);
     }
-    const int qn = (int)qnorm[q];
+    const int qn = qnorm[q];
     int4 o;
     o.x = (j1 == INT_MAX) ? INT_MAX : s1 + qn;
     o.y = (j1 == INT_MAX) ? -1 : j1 + idx_offset;
@@ -713,16 +499,16 @@ ratio_kernel(const int4* __restrict__ in, imatch_segtab seg, double ratio, int* 
     if (threadIdx.x == 0) n_good[blockIdx.x] = (unsigned long long)base_s;
 }
 
-// ---- descriptor upload: u8 / f32 -> bf16 rows + squared norms ------------------------------
+// ---- descriptor upload: u8 / f32 -> int8 rows (x - 128) + squared norms of the shifted rows -----------
 // one wave per row; lane handles 2 values
 template <typename T, bool SEG = false>
-__global__ void pack_rows_kernel(const T* __restrict__ src, int64_t n, int64_t n_pad, uint16_t* __restrict__ dst,
-                                 float* __restrict__ norm, float* __restrict__ hneg, int* __restrict__ flag,
+__global__ void pack_rows_kernel(const T* __restrict__ src, int64_t n, int64_t n_pad, int8_t* __restrict__ dst,
+                                 int* __restrict__ norm, int* __restrict__ tneg, int* __restrict__ flag,
                                  imatch_segtab seg = imatch_segtab(), size_t zs = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n_pad) return;
-    float a = 0.f, b = 0.f;
+    float a = 128.f, b = 128.f;   // a pad row: zero bytes
     bool bad = false;
     if (row < n) {
         const T* s = src + row * 128;
@@ -733,24 +519,23 @@ __global__ void pack_rows_kernel(const T* __restrict__ src, int64_t n, int64_t n
         }
         a = (float)s[2 * lane];
         b = (float)s[2 * lane + 1];
-        // integer in 0..255? decided on the bit patterns: this file is built with -fno-honor-nans (the MFMA kernels' max
-        // trees), under which a float compare may not be relied on to reject a NaN
+        // integer in 0..255? decided on the bit patterns: this file is built with -fno-honor-nans, under which a float
+        // compare may not be relied on to reject a NaN
         auto is_u8 = [](float v) {
             const int i = (int)fminf(fmaxf(v, -1.f), 256.f);   // NaN -> one of the bounds or 0, never a match below
             return i >= 0 && i <= 255 && (__float_as_uint((float)i) == __float_as_uint(v) || __float_as_uint(v) == 0x80000000u);
         };
         bad = !is_u8(a) || !is_u8(b);
     }
-    const __bf16 ha = (__bf16)a, hb = (__bf16)b;
-    const float ra = (float)ha, rb = (float)hb;
-    uint32_t packed = (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
-    ((uint32_t*)dst)[row * 64 + lane] = packed;
-    float s = ra * ra + rb * rb;
+    // (a set with other values is flagged and refused by the kNN entry points; its rows hold the clamped values)
+    const int ia = (int)fminf(fmaxf(a, 0.f), 255.f) - 128, ib = (int)fminf(fmaxf(b, 0.f), 255.f) - 128;
+    ((uint16_t*)dst)[row * 64 + lane] = (uint16_t)((uint32_t)(ia & 0xff) | ((uint32_t)(ib & 0xff) << 8));
+    int s = ia * ia + ib * ib;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) {
-        norm[row] = (row < n) ? s : INFINITY;
-        hneg[row] = (row < n) ? -0.5f * s : -INFINITY;
+        norm[row] = (row < n) ? s : 0;
+        tneg[row] = (row < n) ? -s : KNN_PAD_TNEG;
     }
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(flag, 1);
 }
@@ -762,15 +547,15 @@ int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out) {
     f->n = n;
     f->n_pad = ((n + IMATCH_ROW_PAD - 1) / IMATCH_ROW_PAD) * IMATCH_ROW_PAD;
     if (f->n_pad == 0) f->n_pad = IMATCH_ROW_PAD;
-    // one block: bf16 rows, then norm + hneg (f32 each), then the integrality flag
-    f->desc = (uint16_t*)imatch_pool_alloc(ctx, (size_t)f->n_pad * (256 + 8) + 256);
+    // one block: int8 rows, then norm + tneg (int32 each), then the integrality flag
+    f->desc = (int8_t*)imatch_pool_alloc(ctx, (size_t)f->n_pad * (128 + 8) + 256);
     if (!f->desc) {
         free(f);
         return imatch_set_err(ctx, IMATCH_ENOMEM, "device alloc for %lld descriptors", (long long)n);
     }
-    f->norm = (float*)((char*)f->desc + (size_t)f->n_pad * 256);
-    f->flag = (int*)((char*)f->desc + (size_t)f->n_pad * (256 + 8));
-    f->hneg = f->norm + f->n_pad;
+    f->norm = (int*)((char*)f->desc + (size_t)f->n_pad * 128);
+    f->flag = (int*)((char*)f->desc + (size_t)f->n_pad * (128 + 8));
+    f->tneg = f->norm + f->n_pad;
     *out = f;
     return IMATCH_OK;
 }
@@ -780,7 +565,7 @@ int imatch_features_pack_u8_seg_dev(imatch_ctx* ctx, imatch_features* f, const u
     HIP_TRY(ctx, hipMemsetAsync(f->flag, 0, 256, ctx->stream));
     const unsigned grid = (unsigned)((f->n_pad + 3) / 4);
     hipLaunchKernelGGL((pack_rows_kernel<uint8_t, true>), dim3(grid), dim3(256), 0, ctx->stream, src_dev, f->n, f->n_pad,
-                       f->desc, f->norm, f->hneg, f->flag, *seg, zs);
+                       f->desc, f->norm, f->tneg, f->flag, *seg, zs);
     HIP_TRY(ctx, hipGetLastError());
     f->integral = 1;
     return IMATCH_OK;
@@ -792,7 +577,7 @@ static int features_pack(imatch_ctx* ctx, imatch_features* f, const T* src_dev) 
     const int rows_per_block = 4;
     const unsigned grid = (unsigned)((f->n_pad + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(pack_rows_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, src_dev, f->n, f->n_pad, f->desc,
-                       f->norm, f->hneg, f->flag);
+                       f->norm, f->tneg, f->flag);
     HIP_TRY(ctx, hipGetLastError());
     int flag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&flag, f->flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -801,23 +586,23 @@ static int features_pack(imatch_ctx* ctx, imatch_features* f, const T* src_dev) 
     return IMATCH_OK;
 }
 
-// pad rows of a set whose real rows (bf16 values, norm, -|t|^2/2) were written by their producer (describe_kernel)
-__global__ void pad_rows_kernel(int64_t n, int64_t n_pad, uint16_t* __restrict__ dst, float* __restrict__ norm,
-                                float* __restrict__ hneg, int* __restrict__ flag) {
+// pad rows of a set whose real rows (int8 values, norm, T') were written by their producer (describe_kernel)
+__global__ void pad_rows_kernel(int64_t n, int64_t n_pad, int8_t* __restrict__ dst, int* __restrict__ norm,
+                                int* __restrict__ tneg, int* __restrict__ flag) {
     const int lane = threadIdx.x & 63;
     const int64_t row = n + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;
     if (row >= n_pad) return;
-    ((uint32_t*)dst)[row * 64 + lane] = 0u;
+    ((uint16_t*)dst)[row * 64 + lane] = 0;
     if (lane == 0) {
-        norm[row] = INFINITY;
-        hneg[row] = -INFINITY;
+        norm[row] = 0;
+        tneg[row] = KNN_PAD_TNEG;
     }
 }
 
 int imatch_features_pad_dev(imatch_ctx* ctx, imatch_features* f) {
     const unsigned grid = (unsigned)((f->n_pad - f->n + 3) / 4 + 1);
-    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, f->n, f->n_pad, f->desc, f->norm, f->hneg, f->flag);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, f->n, f->n_pad, f->desc, f->norm, f->tneg, f->flag);
     HIP_TRY(ctx, hipGetLastError());
     f->integral = 1;
     return IMATCH_OK;
@@ -828,7 +613,7 @@ int imatch_features_pack_u8_dev(imatch_ctx* ctx, imatch_features* f, const uint8
     HIP_TRY(ctx, hipMemsetAsync(f->flag, 0, 256, ctx->stream));
     const unsigned grid = (unsigned)((f->n_pad + 3) / 4);
     hipLaunchKernelGGL(pack_rows_kernel<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, src_dev, f->n, f->n_pad, f->desc,
-                       f->norm, f->hneg, f->flag);
+                       f->norm, f->tneg, f->flag);
     HIP_TRY(ctx, hipGetLastError());
     f->integral = 1;
     return IMATCH_OK;
@@ -857,12 +642,11 @@ static int features_from_host(imatch_ctx* ctx, const T* desc, int64_t n, int d, 
     return IMATCH_OK;
 }
 
-// bf16 rows -> u8 rows (integral sets only): the exchange format of the multi-GPU path
-__global__ void unpack_rows_u8_kernel(const uint16_t* __restrict__ src, int64_t n, uint8_t* __restrict__ dst) {
+// int8 rows -> u8 rows (integral sets only): the exchange format of the multi-GPU path; four values per thread
+__global__ void unpack_rows_u8_kernel(const uint32_t* __restrict__ src, int64_t n, uint32_t* __restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * 128) return;
-    const uint32_t u = (uint32_t)src[i] << 16;
-    dst[i] = (uint8_t)__uint_as_float(u);
+    if (i >= n * 32) return;
+    dst[i] = src[i] ^ 0x80808080u;   // x' + 128 on every byte
 }
 
 // ---- launch -------------------------------------------------------------------------------
@@ -894,42 +678,36 @@ int imatch_knn2_scratch_setup(imatch_ctx* ctx) {
 static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t idx_offset,
                     int32_t* out4_dev, void* ws = nullptr, size_t ws_cap = 0) {
     if (!ctx || !q || !t || !out4_dev) return imatch_set_err(ctx, IMATCH_EINVAL, "null argument");
-    // the bf16 rows and the integer casts of the merge are exact only for integers 0..255 (SIFT's descriptors); any other
-    // set would get wrong neighbours with rc 0
+    // the int8 rows hold integers 0..255 (SIFT's descriptors) and nothing else; any other set would get wrong neighbours
+    // with rc 0
     if (!q->integral || !t->integral)
-        return imatch_set_err(ctx, IMATCH_EINVAL, "%s descriptor set is not integer valued in 0..255: the bf16 MFMA kernel is "
-                              "exact only for such sets; use imatch_knn2_f32", !q->integral ? "query" : "train");
+        return imatch_set_err(ctx, IMATCH_EINVAL, "%s descriptor set is not integer valued in 0..255: the int8 MFMA kernel "
+                              "takes only such sets; use imatch_knn2_f32", !q->integral ? "query" : "train");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (q->n == 0) return IMATCH_OK;
-    // query tile per workgroup: 4 waves x 32*QB queries
-    int QB = 4;
-    if (q->n <= 128) QB = 1;
-    else if (q->n <= 512) QB = 2;
-    // QB == 4 (the large-Q case) runs on the 16x16x32 MFMA with 128-row stages (IMATCH_KNN_MFMA16=0: the 32x32x16
-    // kernel, IMATCH_KNN_TN=64: 64-row stages -- both kept for A/B measurements, profiles/r1_knn_shapes.txt)
-    static const int mfma16 = getenv("IMATCH_KNN_MFMA16") ? atoi(getenv("IMATCH_KNN_MFMA16")) : 1;
-    static const int tn_env = getenv("IMATCH_KNN_TN") ? atoi(getenv("IMATCH_KNN_TN")) : 128;
-    static const int xmask = getenv("IMATCH_KNN_XMASK") ? atoi(getenv("IMATCH_KNN_XMASK")) : 7;
+    static const int tn_env = getenv("IMATCH_KNN_TN") ? atoi(getenv("IMATCH_KNN_TN")) : 128;   // 256: A/B runs of the large form
     static const int young = getenv("IMATCH_KNN_YOUNG") ? atoi(getenv("IMATCH_KNN_YOUNG")) : 8;
     static const unsigned young_wg = getenv("IMATCH_KNN_YOUNG_WG") ? (unsigned)atoi(getenv("IMATCH_KNN_YOUNG_WG")) : 0xffffffffu;
-    const bool use16 = mfma16 && QB == 4;
-    const int TNs = (use16 && tn_env == 128 && t->n_pad % 128 == 0) ? 128 : 64;
-    // a single frame's few thousand queries against a map of up to a million rows: 256-query workgroups (QB16 = 4),
-    // twice the workgroups per chunk, so the chunks are twice as long and the resident-query prologue and the partial
-    // lists weigh half as much (0.284 -> 0.242 ms at 2951 x 236k, 0.169 -> 0.127 ms at 2951 x 59k; from 8192 queries
-    // or 5 M rows on the 512-query form is faster, profiles/r1_knn_shapes.txt)
-    static const int64_t q16_small = getenv("IMATCH_KNN_Q16_SMALL") ? atoll(getenv("IMATCH_KNN_Q16_SMALL")) : 6144;
+    // Three forms of one kernel. A single frame's few thousand queries against a map of up to a million rows: 256-query
+    // workgroups (QB = 4), twice the workgroups per chunk, so the chunks are twice as long and the resident-query prologue
+    // and the partial lists weigh half as much; from 6144 queries or 1 M rows on the 512-query form (QB = 8) ...
+    static const int64_t q_small = getenv("IMATCH_KNN_Q16_SMALL") ? atoll(getenv("IMATCH_KNN_Q16_SMALL")) : 6144;
     static const int form_env = getenv("IMATCH_KNN_FORM") ? atoi(getenv("IMATCH_KNN_FORM")) : 0;   // 4 / 8: force a form (A/B runs)
-    bool small16 = use16 && TNs == 128 && q->n <= q16_small && t->n_pad <= (1 << 20);
+    static const double short_pairs = getenv("IMATCH_KNN_SHORT_PAIRS") ? atof(getenv("IMATCH_KNN_SHORT_PAIRS")) : 8e8;
+    bool small = q->n <= q_small && t->n_pad <= (1 << 20);
     bool short8 = false;
     // ... and from about 8e8 (query, row) pairs on -- a frame against a map of a quarter of a million rows or more -- the
     // 512-query form with the 256-query form's first exchange: its stages are twice as long, so the per-tile and per-stage
-    // overheads weigh half as much (2951 x 1 M: 0.664 -> 0.531 ms, 5000 x 236k: 0.268 -> 0.242; 2951 x 236k level,
-    // below that the 256-query form wins: profiles/r2_knn_shapes.txt)
-    if (small16 && (form_env == 8 || (form_env == 0 && (double)q->n * (double)t->n_pad >= 8e8))) { small16 = false; short8 = true; }
-    if (form_env == 8 && use16 && TNs == 128 && q->n <= q16_small) { small16 = false; short8 = true; }
-    if (small16) QB = 2;   // qtile below = 4 * 32 * 2 = 4 waves x 16 * 4 queries
-    const int qtile = 4 * 32 * QB;
+    // overheads weigh half as much (profiles/r2_knn_shapes.txt)
+    if (small && q->n > 256 && (form_env == 8 || (form_env == 0 && (double)q->n * (double)t->n_pad >= short_pairs))) {
+        small = false;
+        short8 = true;
+    }
+    if (form_env == 8 && q->n <= q_small) { small = false; short8 = true; }
+    if (form_env == 4 && q->n <= q_small) { small = true; short8 = false; }
+    const int QB = small ? 4 : 8;
+    const int TNs = (!small && !short8 && tn_env == 256 && t->n_pad % 256 == 0) ? 256 : 128;
+    const int qtile = 4 * 16 * QB;
     const int64_t Qpad = q->n_pad;  // multiple of 1024, so of every qtile
     const int nQt = (int)((q->n + qtile - 1) / qtile);
     const int nStagesAll = (int)(t->n_pad / TNs);
@@ -937,11 +715,11 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     // chunks of a range of stages: a multiple of 8 (one group per XCD); about two workgroups per CU slot; >= 4 stages each
     auto pick_chunks = [&](int nStages) {
         // (rounded DOWN to a multiple of 8, so that the grid stays within two rounds of slots)
-        // -- ONE round for the 256-query form: its launches are short (a frame against a map of well under a million
+        // -- ONE round for the frame forms: their launches are short (a frame against a map of well under a million
         // rows), a second, partly filled round would be a large part of them (1500 x 59k: 54 -> 44 us, 2951 x 59k: 76 -> 67)
-        const bool one_round = small16 || short8;
+        const bool one_round = small || short8;
         int c = (((one_round ? 1 : 2) * slots + (one_round ? 0 : nQt - 1)) / nQt / 8) * 8;
-        // ... and chunks of at most 16k rows (4 MB, one XCD's L2): the query tiles that share a chunk then
+        // ... and chunks of at most 16k rows (2 MB, half an XCD's L2): the query tiles that share a chunk then
         // re-read it from L2 however far apart they run, and the many short workgroups balance the tail
         c = std::max(c, (int)(((int64_t)nStages * TNs + 16383) / 16384 + 7) / 8 * 8);
         c = std::min(c, 256);
@@ -950,79 +728,44 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
         if (const char* e = getenv("IMATCH_KNN_CHUNKS")) c = std::max(8, atoi(e) / 8 * 8);  // tuning override
         return c;
     };
-    // Optional SEED launch (IMATCH_KNN_SEED=<divisor>, off by default): the first rows of the map (at most 1/divisor of it,
-    // one round of short workgroups) matched by a launch of their own, whose chip-wide bound words stay in place for the
-    // main launch over the other rows. Meant for few query tiles, where a tile's workgroups all start at once from loose
-    // bounds; measured it LOSES (2951 x 236k: 0.184 -> 0.198 ms, 4096 x 5 M: 3.02 -> 3.04 ms, profiles/r2_knn_shapes.txt):
-    // the second launch's ramp costs more than the insertion-path blocks it saves. The rotated tile order (rot) is what
-    // helps where the grid runs in many rounds.
-    static const int seed_div = getenv("IMATCH_KNN_SEED") ? atoi(getenv("IMATCH_KNN_SEED")) : 0;
     static const int rot_on = getenv("IMATCH_KNN_ROT") ? atoi(getenv("IMATCH_KNN_ROT")) : 1;
-    int seedStages = 0, seedChunks = 0;
-    if (seed_div > 1 && nQt <= 64 && nStagesAll >= 16 * seed_div) {
-        seedChunks = std::max(8, slots / nQt / 8 * 8);                       // one round of workgroup slots ...
-        seedStages = std::min(nStagesAll / seed_div, seedChunks * 8);        // ... of at most 8 stages each
-        seedChunks = std::max(8, std::min(seedChunks, seedStages / 4) / 8 * 8);
-    }
-    const int nStages = nStagesAll - seedStages;
+    const int nStages = nStagesAll;
     int nChunks = pick_chunks(nStages);
-    const int lists_per_chunk = use16 ? 1 : 2;   // the 16x16x32 kernel merges its four row quarters itself
     const size_t gbytes = ((size_t)Qpad * 12 + 255) & ~(size_t)255;   // three bounds per query
     if (ws) {   // a fixed scratch block: fewer, longer chunks until the partial lists fit
-        const size_t per_chunk = (size_t)lists_per_chunk * Qpad * 16;
+        const size_t per_chunk = (size_t)Qpad * 16;
         const size_t room = ws_cap > gbytes ? (ws_cap - gbytes) / per_chunk : 0;
         if (room < 8)
             return imatch_set_err(ctx, IMATCH_ESIZE, "%lld queries need %zu bytes of kNN scratch, the fixed block holds %zu "
                                   "(at most 262144 queries per call)", (long long)q->n, 8 * per_chunk + gbytes, ws_cap);
-        if ((size_t)(nChunks + seedChunks) > room) {
-            if (room < 16) seedStages = seedChunks = 0;
-            else seedChunks = std::min(seedChunks, 8);
-            nChunks = std::min(nChunks, (int)((room - seedChunks) / 8) * 8);
-        }
+        if ((size_t)nChunks > room) nChunks = (int)(room / 8) * 8;
     }
-    const int64_t nLists = (int64_t)(nChunks + seedChunks) * lists_per_chunk;
+    const int64_t nLists = nChunks;   // the kernel merges its four row quarters itself: one list per chunk
     const size_t pbytes = (size_t)nLists * Qpad * 8;
     if (!ws) {
         int rc = imatch_ws_reserve(ctx, 2 * pbytes + gbytes);
         if (rc) return rc;
         ws = ctx->ws;
     }
-    float2* pb = (float2*)ws;
+    int2* pb = (int2*)ws;
     int2* pi = (int2*)((char*)ws + pbytes);
     int* gthr = (int*)((char*)ws + 2 * pbytes);
-    HIP_TRY(ctx, hipMemsetAsync(gthr, 0x7f, gbytes, ctx->stream));  // 0x7f7f7f7f = 3.39e38 as a float
+    HIP_TRY(ctx, hipMemsetAsync(gthr, 0x7f, gbytes, ctx->stream));  // KNN_INF in every word
     if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    // one launch per range of stages: (first stage, stages, chunks, first partial list)
-    auto launch = [&](int stage0, int nSt, int nCh, int list0) {
-        const unsigned grid = (unsigned)(nQt * nCh);
+    {
+        const unsigned grid = (unsigned)(nQt * nChunks);
         const int rot = rot_on && grid > 2u * slots;
-#define KARGS (const uint4*)q->desc, (const uint4*)t->desc, t->hneg, nQt, nCh, nSt, Qpad, pb, pi, gthr
-        if (use16) {
-            if (small16)
-                hipLaunchKernelGGL((knn2_kernel16<4, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
-                                   stage0, list0, rot);
-            else if (short8)
-                hipLaunchKernelGGL((knn2_kernel16<8, 128, 7, true>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
-                                   stage0, list0, rot);
-            else if (TNs == 128 && xmask == 3)
-                hipLaunchKernelGGL((knn2_kernel16<8, 128, 3>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
-                                   stage0, list0, rot);
-            else if (TNs == 128)
-                hipLaunchKernelGGL((knn2_kernel16<8, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
-                                   stage0, list0, rot);
-            else
-                hipLaunchKernelGGL((knn2_kernel16<8, 64, 3>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, young, young_wg,
-                                   stage0, list0, rot);
-        } else if (QB == 4)
-            hipLaunchKernelGGL((knn2_kernel<4, 64>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, stage0, list0, rot);
-        else if (QB == 2)
-            hipLaunchKernelGGL((knn2_kernel<2, 64>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, stage0, list0, rot);
+#define KARGS (const uint4*)q->desc, (const uint4*)t->desc, t->tneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr, young, young_wg, 0, 0, rot
+        if (small)
+            hipLaunchKernelGGL((knn2_kernel8<4, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS);
+        else if (short8)
+            hipLaunchKernelGGL((knn2_kernel8<8, 128, 7, true>), dim3(grid), dim3(256), 0, ctx->stream, KARGS);
+        else if (TNs == 256)
+            hipLaunchKernelGGL((knn2_kernel8<8, 256, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS);
         else
-            hipLaunchKernelGGL((knn2_kernel<1, 64>), dim3(grid), dim3(256), 0, ctx->stream, KARGS, stage0, list0, rot);
+            hipLaunchKernelGGL((knn2_kernel8<8, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS);
 #undef KARGS
-    };
-    if (seedStages > 0) launch(0, seedStages, seedChunks, 0);
-    launch(seedStages, nStages, nChunks, seedChunks);
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     hipLaunchKernelGGL(knn2_finish_kernel, dim3((unsigned)((q->n + 15) / 16)), dim3(256), 0, ctx->stream, pb, pi,
@@ -1092,8 +835,9 @@ int imatch_features_desc_u8_dev(const imatch_features* f, uint8_t* out_dev) {
     if (!f->integral) return imatch_set_err(ctx, IMATCH_EINVAL, "descriptor set is not integer valued");
     if (f->n == 0) return IMATCH_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(unpack_rows_u8_kernel, dim3((unsigned)((f->n * 128 + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const uint16_t*)f->desc, f->n, out_dev);
+    if ((uintptr_t)out_dev & 3) return imatch_set_err(ctx, IMATCH_EINVAL, "output rows must be 4-byte aligned");
+    hipLaunchKernelGGL(unpack_rows_u8_kernel, dim3((unsigned)((f->n * 32 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)f->desc, f->n, (uint32_t*)out_dev);
     HIP_TRY(ctx, hipGetLastError());
     return IMATCH_OK;
 }

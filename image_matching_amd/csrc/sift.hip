@@ -196,7 +196,7 @@ __device__ __forceinline__ void stage_flush_wave(Rec* stage, int& n_staged, Rec*
     base = __shfl(base, 0);
     wave_lds_fence();
     for (int j = lane; j < n_staged; j += 64)
-        if (base + j < cap) out[base + j] = stage[j];
+        if ((unsigned)(base + j) < (unsigned)cap) out[base + j] = stage[j];   // (a poisoned counter is negative)
     wave_lds_fence();
     n_staged = 0;
 }
@@ -228,7 +228,7 @@ __device__ __forceinline__ void stage_flush_block(const Rec* stage, int n_staged
     int base = wcnt[NW];
     for (int w = 0; w < wv; ++w) base += wcnt[w];
     for (int j = lane; j < n_staged; j += 64)
-        if (base + j < cap) out[base + j] = stage[j];
+        if ((unsigned)(base + j) < (unsigned)cap) out[base + j] = stage[j];   // (a poisoned counter is negative)
 }
 
 // ---- findScaleSpaceExtrema: candidate scan ------------------------------------------------------
@@ -641,8 +641,16 @@ pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* _
     for (int o = o_first; o < o_last; ++o) {
         const int rows = T.rows[o], cols = T.cols[o], n = rows * cols, P = tf_pitch(cols);
         if (SPLIT && o > o_start) {
-            if (tid == 0)
-                while (__hip_atomic_load(ready + (o - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            if (tid == 0) {
+                // bounded (a few seconds): if the flag never comes -- the workgroup before this one never ran -- the candidate
+                // counter's sign bit is set, the kernels behind this one then find nothing to do and the host reports an error
+                // instead of waiting for ever
+                long long spins = 0;
+                while (__hip_atomic_load(ready + (o - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > 4000000) { atomicOr(count, (int)0x80000000); break; }
+                }
+            }
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -969,8 +977,8 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
 #define DESC_HIST (6 * 6 * 10)
 template <int WPK>
 __global__ void __launch_bounds__(256)
-describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first_octave, uint16_t* __restrict__ rows_bf16,
-                float* __restrict__ norm, float* __restrict__ hneg, size_t zs) {
+describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first_octave, int8_t* __restrict__ rows_i8,
+                int* __restrict__ norm, int* __restrict__ tneg, size_t zs) {
     const size_t zo = (size_t)blockIdx.z * zs;
     kps = ZP(kps);
     const int n_kp = seg.off[blockIdx.z + 1] - seg.off[blockIdx.z];
@@ -1145,22 +1153,22 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
     for (int o = 32; o > 0; o >>= 1) nrm2 += __shfl_xor(nrm2, o);
     nrm2 = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
     // The quantised descriptor goes straight into the matcher's row format (what pack_rows_kernel made of the u8 rows in a
-    // pass of its own: 0.2 ms of a 64-frame batch): bf16 values -- exact for integers 0..255, the upper half of the f32
-    // pattern --, the squared norm and -|t|^2/2 of the row (integer sums below 2^24: any order gives the same float).
+    // pass of its own: 0.2 ms of a 64-frame batch): int8 values x - 128, the squared norm of that shifted row and its
+    // negative (common.h, imatch_features).
     if (active) {
         const size_t row = (size_t)seg.off[blockIdx.z] + (size_t)id;
-        float s2 = 0.f;
+        int s2 = 0;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float q = (float)min(max(__float2int_rn(v[e] * nrm2), 0), 255);
-            rows_bf16[row * 128 + lane + 64 * e] = (uint16_t)(__float_as_uint(q) >> 16);
-            s2 += q * q;
+            const int qi = min(max(__float2int_rn(v[e] * nrm2), 0), 255) - 128;
+            rows_i8[row * 128 + lane + 64 * e] = (int8_t)qi;
+            s2 += qi * qi;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
         if (lane == 0) {
             norm[row] = s2;
-            hneg[row] = -0.5f * s2;
+            tneg[row] = -s2;
         }
     }
 }
@@ -1826,6 +1834,8 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         const double t_b = now_ms();
         int max_cand = 0, max_ref = 0, max_kp = 0;
         for (int b = 0; b < batch; ++b) {
+            if (h_cnt[4 * b] < 0)
+                return imatch_set_err(ctx, IMATCH_EHIP, "scale space, small octaves: a workgroup waited in vain for the octave before it");
             max_cand = std::max(max_cand, h_cnt[4 * b]);
             max_ref = std::max(max_ref, h_cnt[4 * b + 1]);
             max_kp = std::max(max_kp, h_cnt[4 * b + 2]);
@@ -1963,13 +1973,13 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             const int wpk = wpk_env ? wpk_env : 4;
             if (wpk == 4)
                 hipLaunchKernelGGL(describe_kernel<4>, dim3(max_k, 1, batch), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted,
-                                   seg, first_octave, f->desc, f->norm, f->hneg, zs);
+                                   seg, first_octave, f->desc, f->norm, f->tneg, zs);
             else if (wpk == 2)
                 hipLaunchKernelGGL(describe_kernel<2>, dim3((max_k + 1) / 2, 1, batch), dim3(256), 0, ctx->stream, T,
-                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->hneg, zs);
+                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs);
             else
                 hipLaunchKernelGGL(describe_kernel<1>, dim3((max_k + 3) / 4, 1, batch), dim3(256), 0, ctx->stream, T,
-                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->hneg, zs);
+                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs);
             HIP_TRY(ctx, hipGetLastError());
         }
         // the set's pad rows and flag (u8 rows are integral by type)
@@ -2027,15 +2037,13 @@ int imatch_features_download(const imatch_features* f, float* kp, float* desc) {
     }
     if (desc && f->n > 0) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
-        int rc = imatch_hs_reserve(ctx, (size_t)f->n * 256);
+        if (!f->integral) return imatch_set_err(ctx, IMATCH_EINVAL, "descriptor set is not integer valued: its rows were not kept");
+        int rc = imatch_hs_reserve(ctx, (size_t)f->n * 128);
         if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->hs, f->desc, (size_t)f->n * 256, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->hs, f->desc, (size_t)f->n * 128, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        const uint16_t* b = (const uint16_t*)ctx->hs;
-        for (size_t i = 0; i < (size_t)f->n * 128; ++i) {
-            const uint32_t u = (uint32_t)b[i] << 16;
-            memcpy(&desc[i], &u, 4);
-        }
+        const int8_t* b = (const int8_t*)ctx->hs;   // stored as value - 128
+        for (size_t i = 0; i < (size_t)f->n * 128; ++i) desc[i] = (float)((int)b[i] + 128);
     }
     return IMATCH_OK;
 }

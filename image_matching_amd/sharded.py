@@ -110,6 +110,9 @@ class ShardedMatcher:
                 t = torch.zeros(shape, dtype=dtype, pin_memory=self.device.type == "cuda")
             else:
                 t = torch.zeros(shape, dtype=dtype, device=self.device)
+                if self.device.type == "cuda":
+                    # the fill runs on torch's stream, the buffer's first user on the context's: once per buffer, wait
+                    torch.cuda.current_stream(self.device).synchronize()
             self._bufs[key] = t
         return t
 

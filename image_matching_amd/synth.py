@@ -73,6 +73,8 @@ def synth_descriptors_dev(lo, hi, device, seed=7):
         a, b = max(lo, c * DEV_CHUNK), min(hi, (c + 1) * DEV_CHUNK)
         if b > a:
             out[a - lo:b - lo] = u[a - c * DEV_CHUNK:b - c * DEV_CHUNK]
+    if out.is_cuda:
+        torch.cuda.synchronize(out.device)   # made on torch's stream; its readers (a Context's own stream) come after this
     return out
 
 
@@ -106,6 +108,8 @@ def synth_queries_dev(train, nq, seed=8, noise=6, n_dup=0):
         train[src[sel]] = q[sel]
         train[hi_rows[sel]] = q[sel]
         dup[sel] = hi_rows[sel]
+    if q.is_cuda:
+        torch.cuda.synchronize(q.device)   # as above: complete before a Context's stream reads q and train
     return q, src, dup
 
 

@@ -48,6 +48,7 @@ def test_batch_of_one_and_ragged_pitch(ctx, scene):
         pad = np.zeros((240, 384), np.uint8)
         pad[:, :320] = frames[b]
         buf[b, :240 * 384] = torch.from_numpy(pad.reshape(-1)).to(dev)
+    torch.cuda.synchronize()   # torch's fills ran on its stream; the context's (non-blocking) stream reads the buffer next
     f, offs = ctx.sift_extract_batch_dev(buf.data_ptr(), 3, 102400, 240, 320, 384)
     kp, desc = f.download()
     for b in range(3):
@@ -154,6 +155,7 @@ def test_batch_of_128_images_through_the_whole_chain_and_257_refused(ctx, scene)
         one.free()
     f.free()
     big = torch.zeros((257, 64 * 64), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
     with pytest.raises(Exception):
         ctx.sift_extract_batch_dev(big.data_ptr(), 257, 64 * 64, 64, 64, 64)
     f_map.free()

@@ -29,7 +29,7 @@ def test_bench_line(capsys, monkeypatch):
     assert out["data"] == "synthetic" and "workload" in out["config"] and "model" not in out["config"]
     assert abs(out["value"] - 8 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     r = out["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 5000.0 and out["dtype"] == "i8"
     assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]

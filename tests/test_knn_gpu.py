@@ -134,6 +134,7 @@ def test_large_map_properties(ctx):
     q_dev = t_dev[src].clone()
     hi = src + 12345
     t_dev[hi] = q_dev  # a duplicate at a higher index: exact tie at distance 0
+    torch.cuda.synchronize()   # torch filled these on ITS stream; the context's stream reads them next
     ft = ctx.features_from_device_u8(t_dev.data_ptr(), n)
     fq = ctx.features_from_device_u8(q_dev.data_ptr(), nq)
     out4 = torch.empty((nq, 4), dtype=torch.int32, device="cuda:0")
@@ -158,7 +159,7 @@ def test_large_map_properties(ctx):
 
 def test_fractional_rows_are_refused_by_the_mfma_entry_point_and_rerouted_by_the_facade(ctx):
     """128 floats per row that are not integers 0..255 (RootSIFT, normalised rows): imatch_knn2 must not answer with
-    bf16-rounded neighbours and rc 0 -- the C call errors, the facade sends the matrices through the float kernel and
+    clamped int8 neighbours and rc 0 -- the C call errors, the facade sends the matrices through the float kernel and
     gives BFMatcher's f32 answer (match_finder.py:182-183)."""
     import image_matching_amd as im
     from image_matching_amd.match_finder import match_finder

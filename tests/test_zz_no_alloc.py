@@ -53,11 +53,13 @@ def test_no_alloc_entry_point_many_queries_fewer_chunks_and_limit(ctx):
     rows = torch.randint(0, 300_000, (150_000,), device="cuda:0", generator=g)
     q_dev = t_dev[rows].clone()
     q_dev[:, :4] = torch.randint(0, 256, (150_000, 4), dtype=torch.uint8, device="cuda:0", generator=g)
+    torch.cuda.synchronize()   # torch's stream made these; the context's stream reads them
     ft = ctx.features_from_device_u8(t_dev.data_ptr(), 300_000)
     fq = ctx.features_from_device_u8(q_dev.data_ptr(), 150_000)
     a, b = _both(ctx, torch, fq, ft, 150_000)
     assert np.array_equal(a, b)
     big = torch.zeros((262_145, 128), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
     fbig = ctx.features_from_device_u8(big.data_ptr(), 262_145)
     out = torch.empty((262_145, 4), dtype=torch.int32, device="cuda:0")
     with pytest.raises(im.ImatchError, match="at most 262144"):
