@@ -82,7 +82,10 @@ __device__ __forceinline__ int bound_g(int T) { return -((T + 1) >> 1); }
 #ifdef KNN_TRACE   // development only (tools/dbg/knn_trace.py): per-workgroup wall-clock stamps (100 MHz)
 #define KNN_TRACE_SLOTS 40
 __device__ long long knn_trace[2048 * KNN_TRACE_SLOTS];
-#define KT(slot) do { if (threadIdx.x == 0 && blockIdx.x < 2048 && (slot) < KNN_TRACE_SLOTS) \
+#ifndef KT_AGE0
+#define KT_AGE0 0     // first stage (age in its chunk) whose stamps are kept
+#endif
+#define KT(slot) do { if (threadIdx.x == 0 && blockIdx.x < 2048 && (slot) >= 0 && (slot) < KNN_TRACE_SLOTS) \
         knn_trace[blockIdx.x * KNN_TRACE_SLOTS + (slot)] = (long long)wall_clock64(); } while (0)
 extern "C" int imatch_dbg_knn_trace(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(knn_trace), sizeof(long long) * 2048 * KNN_TRACE_SLOTS);
@@ -217,9 +220,11 @@ knn2_kernel8(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const i
     if (s_begin < s_end) stage(s_begin, 0);
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
+        KT(4 + 3 * (s - s_begin - KT_AGE0));   // stamps per stage: top, own loads landed, barrier released
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KT(5 + 3 * (s - s_begin - KT_AGE0));
         __syncthreads();
-        KT(4 + 2 * (s - s_begin));
+        KT(6 + 3 * (s - s_begin - KT_AGE0));
         const int age = s - s_begin;
         // every stage while the chunk is young -- only workgroups of the first rounds start from loose bounds, later ones
         // inherit the chip-wide words -- then XM + 1 stages between bound exchanges
@@ -289,7 +294,6 @@ knn2_kernel8(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const i
             }
         };
 
-        KT(5 + 2 * (s - s_begin));
         load_tile(0);
         i32x4 acc0 = chain(0), acc1;
         if (KEY0 && age == 0 && young_now) {
@@ -756,14 +760,17 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
         const unsigned grid = (unsigned)(nQt * nChunks);
         const int rot = rot_on && grid > 2u * slots;
 #define KARGS (const uint4*)q->desc, (const uint4*)t->desc, t->tneg, nQt, nChunks, nStages, Qpad, pb, pi, gthr, young, young_wg, 0, 0, rot
+        // (development: extra dynamic LDS per workgroup, i.e. fewer workgroups per CU: 1 / 2 / 3 per CU give 28 / 51 / 59 %
+        // of the int8 peak at the bench shape)
+        static const unsigned dyn = getenv("IMATCH_KNN_DYNLDS") ? (unsigned)atoi(getenv("IMATCH_KNN_DYNLDS")) : 0;
         if (small)
-            hipLaunchKernelGGL((knn2_kernel8<4, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS);
+            hipLaunchKernelGGL((knn2_kernel8<4, 128, 7>), dim3(grid), dim3(256), dyn, ctx->stream, KARGS);
         else if (short8)
-            hipLaunchKernelGGL((knn2_kernel8<8, 128, 7, true>), dim3(grid), dim3(256), 0, ctx->stream, KARGS);
+            hipLaunchKernelGGL((knn2_kernel8<8, 128, 7, true>), dim3(grid), dim3(256), dyn, ctx->stream, KARGS);
         else if (TNs == 256)
-            hipLaunchKernelGGL((knn2_kernel8<8, 256, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS);
+            hipLaunchKernelGGL((knn2_kernel8<8, 256, 7>), dim3(grid), dim3(256), dyn, ctx->stream, KARGS);
         else
-            hipLaunchKernelGGL((knn2_kernel8<8, 128, 7>), dim3(grid), dim3(256), 0, ctx->stream, KARGS);
+            hipLaunchKernelGGL((knn2_kernel8<8, 128, 7>), dim3(grid), dim3(256), dyn, ctx->stream, KARGS);
 #undef KARGS
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -1,4 +1,6 @@
-"""Development: per-workgroup time stamps of the 16x16x32 kNN kernel (library built with -DKNN_TRACE for knn.hip).
+"""Development: per-workgroup time stamps of the kNN kernel (library built with -DKNN_TRACE for knn.hip, tools/dbg/build_trace.sh).
+Stamps of wave 0: 0 start, 1 prologue done, 2 last stage done, 3 end; per stage k: 4+3k top (compute of the stage before is
+done), 5+3k its own loads have landed, 6+3k the workgroup's barrier has released.
 Usage: python tools/dbg/knn_trace.py Q N"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -24,22 +26,21 @@ buf = np.zeros(2048 * SL, dtype=np.int64)
 rc = lib.imatch_dbg_knn_trace(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
 tr = buf.reshape(2048, SL)
-live = tr[:, 0] > 0
-tr = tr[live]
+tr = tr[tr[:, 3] > 0]
 t0 = tr[:, 0].min()
 us = lambda x: (x - t0) / 100.0
 print("workgroups traced:", len(tr))
 print("start   : min %.1f  median %.1f  max %.1f us" % (us(tr[:, 0]).min(), np.median(us(tr[:, 0])), us(tr[:, 0]).max()))
 print("prologue: median %.2f us (max %.2f)" % (np.median(tr[:, 1] - tr[:, 0]) / 100, (tr[:, 1] - tr[:, 0]).max() / 100))
-nst = ((tr[:, 4::2] > 0).sum(axis=1))
-print("stages per workgroup: min %d max %d" % (nst.min(), nst.max()))
-for k in range(int(nst.max())):
-    ok = nst > k
-    top = tr[ok, 4 + 2 * k]
-    cmp_ = tr[ok, 5 + 2 * k]
-    nxt = np.where(nst[ok] > k + 1, tr[ok, 4 + 2 * (k + 1)] if 4 + 2 * (k + 1) < SL else tr[ok, 2], tr[ok, 2])
-    prev = tr[ok, 1] if k == 0 else tr[ok, 5 + 2 * (k - 1)]
-    print("stage %2d: wait+barrier (from prev compute start) %.2f us, exchange %.2f us, compute->next top %.2f us   [n=%d]"
-          % (k, np.median(top - prev) / 100, np.median(cmp_ - top) / 100, np.median(nxt - cmp_) / 100, ok.sum()))
-print("merge+write: median %.2f us" % (np.median(tr[:, 3] - tr[:, 2]) / 100))
+K = (SL - 4) // 3
+for k in range(K):
+    top, landed, rel = tr[:, 4 + 3 * k], tr[:, 5 + 3 * k], tr[:, 6 + 3 * k]
+    ok = (top > 0) & (rel > 0)
+    if not ok.any():
+        break
+    nxt = tr[:, 4 + 3 * (k + 1)] if k + 1 < K else tr[:, 2]
+    ok2 = ok & (nxt > 0)
+    print("stage %2d: wait for loads %.2f us, barrier %.2f us, exchange+compute %.2f us   [n=%d]"
+          % (k, np.median((landed - top)[ok]) / 100, np.median((rel - landed)[ok]) / 100,
+             np.median((nxt - rel)[ok2]) / 100 if ok2.any() else float("nan"), ok.sum()))
 print("workgroup total: median %.1f us, max %.1f us; last end at %.1f us" % (np.median(tr[:, 3] - tr[:, 0]) / 100, (tr[:, 3] - tr[:, 0]).max() / 100, us(tr[:, 3]).max()))
