@@ -694,13 +694,13 @@ def main():
             # default run is workload c1 (a 236 k-row map), so value(N) / value(1) of the default series compares two
             # workloads; this is the single-GPU point of THIS one. Not measured in this run.
             try:
-                with open(os.path.join(ROOT, "profiles", "r2d_bench_c3_n1.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r2e_bench_c3_n1.json")) as fh:
                     one = json.load(fh)
                 if workload == "c3" and one["config"]["map_descriptors"] == n_map and \
                         one["config"]["frames_per_step_per_gpu"] == B * n_streams:
                     multi["same_workload_on_one_gpu"] = {
                         "value": one["value"], "unit": "frames/s", "ms_per_step": one["ms_per_step"],
-                        "source": "profiles/r2d_bench_c3_n1.json (bench.py --workload c3 --gpus 1), not measured in this run"}
+                        "source": "profiles/r2e_bench_c3_n1.json (bench.py --workload c3 --gpus 1), not measured in this run"}
             except (OSError, ValueError, KeyError):
                 pass
         # HBM-side traffic of the dominant kernel: NOT measured in this run -- it comes from separate rocprofv3 --pmc passes

@@ -153,7 +153,7 @@ def _ptr(a, t):
 
 
 class Features:
-    """A descriptor set resident in HBM (bf16 rows + squared norms). Outlives the call that made
+    """A descriptor set resident in HBM (int8 rows = value - 128, + squared norms). Outlives the call that made
     it, so `find_matches` need not upload again (the reference re-uploads on every call,
     match_finder.py:187-188)."""
 

@@ -1,6 +1,6 @@
 // Brute-force kNN (k = 2) for float descriptors of any length up to 128 -- the matcher of the AKAZE path (SURVEY 8f
 // rank 3): cv2.BFMatcher(cv2.NORM_L2).knnMatch(descriptors_1, roi.dp, k=2) (match_finder.py:182-183) on the 64-float
-// M-SURF descriptors the checked-in detector produces. These are not small integers, so the bf16 MFMA kernel of knn.hip
+// M-SURF descriptors the checked-in detector produces. These are not small integers, so the int8 MFMA kernel of knn.hip
 // (exact only for 0..255 values) does not apply; this one computes sum_k (q_k - t_k)^2 in f32 in index order, one
 // sequential chain per pair -- the order of oracle_knn2 -- so distances, indices and ties are bit-identical to the oracle.
 // fp32 VALU-bound: 1.5 packed instructions per pair and dimension, operands from LDS tiles stored dimension-major.

@@ -184,7 +184,7 @@ class match_finder():
             return self.ctx.knn2_f32(query_dp, train_dp)
         fq, ft = _features_of(self.ctx, query_dp), _features_of(self.ctx, train_dp)
         if fq.integral and ft.integral:
-            return self.ctx.knn2(fq, ft)      # SIFT's integer rows: bf16 MFMA, exact
+            return self.ctx.knn2(fq, ft)      # SIFT's integer rows: int8 MFMA, exact
         # 128 floats per row that are not integers 0..255 (RootSIFT, normalised rows, SURF-128): the MFMA kernel would
         # round them; BFMatcher's f32 arithmetic is the float kernel's (match_finder.py:182-183)
         return self.ctx.knn2_f32(np.asarray(query_dp, dtype=np.float32), np.asarray(train_dp, dtype=np.float32))

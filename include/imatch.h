@@ -56,7 +56,8 @@ int imatch_sift_pyramid_ms(imatch_ctx* ctx, float* ms);
 
 /* Descriptor sets resident in HBM ----------------------------------------- */
 /* Replaces cv2.cuda_GpuMat(descriptors) (MF:187-188), but the set outlives the call:
- * rows are stored as bf16 [n_pad][128] (exact for 0..255 integers) plus f32 squared norms. */
+ * rows are stored as int8 [n_pad][128] (value - 128, for values that are integers 0..255) plus int32 squared norms of the
+ * shifted rows: the matcher runs on the int8 MFMA in exact integer arithmetic. */
 int imatch_features_from_host_f32(imatch_ctx* ctx, const float* desc, int64_t n, int d, imatch_features** out);
 int imatch_features_from_host_u8(imatch_ctx* ctx, const uint8_t* desc, int64_t n, int d, imatch_features** out);
 /* Same, from a u8 [n][128] matrix already in device memory (a torch tensor's data_ptr). */

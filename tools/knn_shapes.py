@@ -42,6 +42,7 @@ def main():
             kern.append(ctx.knn2_kernel_ms())
         ms = e0.elapsed_time(e1) / reps
         k = min(kern)
+        # (against the bf16 peak, as every earlier table in profiles/ is; the int8 peak the kernel runs on is twice that)
         print("Q=%-7d N=%-9d call %.3f ms  mfma launch(es) %.3f ms  %.1f Gdist/s  %.1f%% of 2.5 PF (launches alone %.1f%%)"
               % (nq, n, ms, k, nq * n / ms / 1e6, nq * n * 256 / ms / 1e9 / 2500 * 100, nq * n * 256 / k / 1e9 / 2500 * 100), flush=True)
         ft.free()
