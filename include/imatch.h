@@ -70,7 +70,8 @@ int imatch_features_from_device_u8(imatch_ctx* ctx, const uint8_t* desc_dev, int
 int imatch_features_from_device_u8_seg(imatch_ctx* ctx, const uint8_t* desc_dev, int n_seg, const int64_t* counts,
                                        size_t seg_pitch, int d, imatch_features** out);
 /* Writes the set as u8 [n][128] into device memory (asynchronously, on the context's stream): the
- * exchange format of the multi-GPU path (queries are all-gathered as bytes). Integral sets only. */
+ * exchange format of the multi-GPU path (queries are all-gathered as bytes). Integral sets only; out_dev must be
+ * 4-byte aligned (the rows go out a word at a time). */
 int imatch_features_desc_u8_dev(const imatch_features* f, uint8_t* out_dev);
 int64_t imatch_features_count(const imatch_features* f);
 /* 1 when every descriptor value of the set is an integer in 0..255 (kNN is then bit-exact), else 0. */
