@@ -301,6 +301,9 @@ def main():
     replicated_frames = workload == "c5"
     B = args.batch if args.batch > 0 else (32 if workload == "c5" else 256 if workload == "c1" else 64)
 
+    if os.environ.get("IMATCH_BENCH_STACKS"):      # development: every thread's Python stack on stderr after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["IMATCH_BENCH_STACKS"]), exit=False)
     import image_matching_amd as im
     from image_matching_amd import sharded, synth
     ctx = im.Context(local_rank)

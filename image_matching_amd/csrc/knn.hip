@@ -73,6 +73,10 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 
 typedef int __attribute__((ext_vector_type(4))) i32x4;
 
+#ifndef KNN_TILE_PAIRS
+#define KNN_TILE_PAIRS 1   // 0: the one-tile main loop (kept for A/B builds)
+#endif
+
 #define KNN_INF 0x7f7f7f7f            // "no bound yet" / an empty list slot (what hipMemset 0x7f leaves in a word)
 #define KNN_PAD_TNEG (-(1 << 24))     // T' of a pad row
 
@@ -99,13 +103,14 @@ extern "C" int imatch_dbg_knn_trace(long long* out) {
 // SHORT: the 512-query form for a few query tiles against chunks of a few dozen stages (a frame against a large map):
 // the 256-query form's first exchange (merged publishing, waited for) without its key registers.
 template <int QB, int TN, int XM, bool SHORT = false>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, TN <= 128 ? 3 : 2)   // three workgroups per CU (40 KB of LDS each, <= 168 VGPRs)
 knn2_kernel8(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const int* __restrict__ tneg,
              int nQt, int nChunks, int nStages, int64_t Qpad, int2* __restrict__ pb, int2* __restrict__ pi,
              int* __restrict__ gthr, int young, unsigned young_wg, int stage0, int list0, int rot) {
     static_assert(QB % 4 == 0, "bounds are fetched 64 queries at a time");
     static_assert(TN <= 128 || QB > 4, "the first-stage keys hold a 7-bit row");
     static_assert(TN % 64 == 0, "the T' words of a stage are loaded 64 at a time");
+    static_assert((TN / 16) % 2 == 0 && QB % 2 == 0, "the main loop walks pairs of tiles with two accumulator sets");
     // the key form of a young chunk's first stage (below) costs 2 * QB registers and is worth them where chunks are short
     constexpr bool KEY0 = QB <= 4;
     constexpr bool MERGED = KEY0 || SHORT;   // lane-merged publishing; the second stage waits for the first exchange
@@ -268,9 +273,8 @@ knn2_kernel8(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const i
         };
         // Insertion path (rare, wave-uniform entry). Rows are visited in ascending train index with strict <: OpenCV's
         // lowest-index tie-break.
-        auto epilogue = [&](const i32x4& a, int qb, int tile) {
-            const int m = max(max(a[0], a[1]), max(a[2], a[3]));
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= G[qb]) != 0, 0)) {   // rare: keep the hot path the fall-through
+        auto insert_block = [&](const i32x4& a, int qb, int tile) {
+            {
                 int rowbase = s * TN + tile * 16 + 4 * q;
                 asm volatile("" : "+v"(rowbase));
                 const uint4 tw = img[TN * 8 + tile * 4 + q];   // the rows' parity bits (the tile's T' words again)
@@ -293,7 +297,67 @@ knn2_kernel8(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const i
                 G[qb] = max(g, bound_g(b2[qb]));
             }
         };
+        auto epilogue = [&](const i32x4& a, int qb, int tile) {
+            const int m = max(max(a[0], a[1]), max(a[2], a[3]));
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= G[qb]) != 0, 0))   // rare: keep the hot path the fall-through
+                insert_block(a, qb, tile);
+        };
 
+#if KNN_TILE_PAIRS
+        // (not in the short-chunk form: with the merged publishing's registers on top it would spill 44 of them)
+        if (!SHORT && !(KEY0 && age == 0 && young_now)) {
+            // Main loop on PAIRS OF TILES: a query block meets tiles 2p and 2p+1 back to back, and their eight results per
+            // lane are examined by ONE compare and one branch (same queries, same bound) -- 2.5 vector instructions per
+            // block instead of 3 and half the branches, which is where this kernel's time goes (profiles/r2e_pmc_knn_mfma.md);
+            // the four MFMAs of a step alternate between the two tiles, so no MFMA follows the one it depends on.
+            i32x4 afA[2], afB[2], tinA, tinB;
+            auto load_pair = [&](int tp) {
+                const unsigned a0 = (unsigned)tp * 4096u + frag_off;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    uint4 u = *(const uint4*)((const char*)img + (a0 ^ (unsigned)(t << 6)));
+                    afA[t] = __builtin_bit_cast(i32x4, u);
+                    uint4 w = *(const uint4*)((const char*)img + ((a0 + 2048u) ^ (unsigned)(t << 6)));
+                    afB[t] = __builtin_bit_cast(i32x4, w);
+                }
+                const uint4 ua = img[TN * 8 + tp * 8 + (int)(lf >> 4)], ub = img[TN * 8 + tp * 8 + 4 + (int)(lf >> 4)];
+                tinA = __builtin_bit_cast(i32x4, ua) >> 1;
+                tinB = __builtin_bit_cast(i32x4, ub) >> 1;
+            };
+            auto chain2 = [&](int qb, i32x4 (&x)[2]) {
+                x[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afA[0], qf[qb][0], tinA, 0, 0, 0);
+                x[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afB[0], qf[qb][0], tinB, 0, 0, 0);
+                x[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afA[1], qf[qb][1], x[0], 0, 0, 0);
+                x[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afB[1], qf[qb][1], x[1], 0, 0, 0);
+            };
+            auto epilogue2 = [&](const i32x4 (&x)[2], int qb, int tp) {
+                int m = max(max(x[0][0], x[0][1]), max(x[0][2], x[0][3]));
+                m = max(max(m, x[1][0]), max(x[1][1], max(x[1][2], x[1][3])));
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= G[qb]) != 0, 0)) {
+                    insert_block(x[0], qb, 2 * tp);        // ascending rows: the lower tile first
+                    insert_block(x[1], qb, 2 * tp + 1);
+                }
+            };
+            i32x4 P[2][2];
+            load_pair(0);
+            chain2(0, P[0]);
+#pragma unroll 1
+            for (int tp = 0; tp < NT / 2; ++tp) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    const int cs = qb & 1, ns = cs ^ 1;      // QB is even: a tile pair's first block is always in set 0
+                    if (qb + 1 < QB) chain2(qb + 1, P[ns]);
+                    else if (tp + 1 < NT / 2) {               // the pair's last chains are out: the next pair's operands
+                        load_pair(tp + 1);
+                        chain2(0, P[ns]);
+                    }
+                    epilogue2(P[cs], qb, tp);
+                }
+            }
+            if (MERGED && age == 0 && young_now && young > 1) publish_bounds();
+            continue;
+        }
+#endif
         load_tile(0);
         i32x4 acc0 = chain(0), acc1;
         if (KEY0 && age == 0 && young_now) {

@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include <chrono>
@@ -1477,6 +1478,10 @@ extern "C" {
 // offsets[b] .. offsets[b+1] are image b's rows (and keypoint records).
 static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, int batch, size_t img_pitch, int h, int w,
                         int stride, const imatch_sift_params* P, imatch_features** out, int64_t* offsets) {
+    // IMATCH_DEBUG_STEPS=1: a line on stderr at every point where the host may wait (to place a hang)
+    static const bool dbg_steps = getenv("IMATCH_DEBUG_STEPS") != nullptr;
+#define DBG_STEP(msg) do { if (dbg_steps) { fprintf(stderr, "[imatch %d] sift_extract: %s\n", (int)getpid(), msg); fflush(stderr); } } while (0)
+    DBG_STEP("enter");
     if (!ctx || !img || !P || !out || h <= 0 || w <= 0 || stride < w || batch < 1)
         return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
     if (batch > IMATCH_MAX_BATCH) return imatch_set_err(ctx, IMATCH_ESIZE, "batch %d above %d", batch, IMATCH_MAX_BATCH);
@@ -1555,7 +1560,9 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         const size_t zs = (off + 4095) & ~(size_t)4095;   // bytes between the blocks of consecutive images
         const size_t need = zs * (size_t)batch;
         if (need > S->arena_bytes) {
+            DBG_STEP("arena grows: sync");
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            DBG_STEP("arena grows: free + malloc");
             if (S->arena) HIP_TRY(ctx, hipFree(S->arena));
             S->arena = nullptr;
             S->arena_bytes = 0;
@@ -1591,7 +1598,9 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             HIP_TRY(ctx, hipMemcpy2DAsync(d_img, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyDeviceToDevice,
                                           ctx->stream));
         } else {
+            DBG_STEP("arena ready: upload");
             int rcu = imatch_stage_upload(ctx, img, h, w, stride, d_img);   // consumed before this call's synchronisation
+            DBG_STEP("upload queued");
             if (rcu) return rcu;
         }
         if (P->clahe) {
@@ -1629,16 +1638,24 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         bool split = all_templated && n_oct > 1 && !use_side && o_tail >= 1 && nl == 3;
         if (const char* e = getenv("IMATCH_SIFT_SPLIT")) split = split && atoi(e) != 0;        // experiments
         if ((use_side || split) && !S->side) {
-            // highest priority: the later octaves' small launches must get CU slots while octave 0's big kernels
-            // are resident, or they queue behind them and the overlap is lost
+            // Default priority. (Rounds 1-2 created this stream at the highest priority so that the later octaves' small
+            // launches would get CU slots beside octave 0's big kernels. With TWO processes on one GPU -- the rehearsal
+            // form of bench.py -- that deadlocked about one run in five: a rank's first extraction never finished, its
+            // queues stuck behind the other process's; forty runs without the priority were clean, and one process alone
+            // is no slower without it: bench 7896 against 7778 frames/s, a frame 0.66 against 0.71 ms, the 8192^2 map's
+            // scale space 6.65 against 6.44 ms. IMATCH_SIFT_SIDE_PRIO=1 brings the old behaviour back for measurements.)
             int prio_least = 0, prio_greatest = 0;
+            DBG_STEP("second stream: create");
             HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-            HIP_TRY(ctx, hipStreamCreateWithPriority(&S->side, hipStreamNonBlocking, prio_greatest));
+            static const int side_prio = getenv("IMATCH_SIFT_SIDE_PRIO") ? atoi(getenv("IMATCH_SIFT_SIDE_PRIO")) : 0;
+            if (side_prio) HIP_TRY(ctx, hipStreamCreateWithPriority(&S->side, hipStreamNonBlocking, prio_greatest));
+            else HIP_TRY(ctx, hipStreamCreateWithFlags(&S->side, hipStreamNonBlocking));
             HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming));
         }
         if (split && !S->have_ev_oct) {
             for (int o = 0; o < MAX_OCT; ++o) HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_oct[o], hipEventDisableTiming));
+            DBG_STEP("second stream and events created");
             S->have_ev_oct = true;
         }
         hipStream_t st2 = use_side ? S->side : ctx->stream;
@@ -1726,6 +1743,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             if (n / 2 != want_r[i]) tail_fast = false;
             else memcpy(tfk.k[i - 1], kk, sizeof(float) * n);
         }
+        DBG_STEP("large octaves queued");
         if (tail_fast) {
             static bool attr_set[64] = {false};
             if (!attr_set[ctx->device & 63]) {
@@ -1765,6 +1783,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             HIP_TRY(ctx, hipEventRecord(S->ev_join, S->side));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, S->ev_join, 0));
         }
+        DBG_STEP("small octaves queued");
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
         // ---- refine + orientation are queued behind the scan without waiting for its count
         // (grid from the previous extraction's candidate count -- the kernel strides: sized by the list's CAPACITY, a batch
@@ -1780,6 +1799,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // frames: sorted, deduplicated and rescaled where they lie (sort_dedupe_kernel); maps keep the host's radix sort
         KpRec* d_sorted = (KpRec*)d_ref;   // the refined list is no longer needed once the orientations are out
         static const int dev_sort_env = getenv("IMATCH_SIFT_DEVSORT") ? atoi(getenv("IMATCH_SIFT_DEVSORT")) : 1;
+        DBG_STEP("refinement and orientation queued");
         const int n_sort = std::min(SORT_CAP, S->kp_hint > 0 ? S->kp_hint : 4096);   // records the device sort is launched for
         bool dev_sort = dev_sort_env && (size_t)SORT_CAP * sizeof(KpRec) <= (size_t)cap * sizeof(RefinedKp) &&
                         (S->kp_hint > 0 ? S->kp_hint <= SORT_CAP + SORT_CAP / 4 + 1024 : (size_t)h * w <= ((size_t)1 << 21));
@@ -1800,8 +1820,10 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         int kp_hint = std::min(2 * cap, S->kp_hint > 0 ? S->kp_hint : 8192);
         if (dev_sort) kp_hint = std::min(kp_hint, SORT_CAP);
         const size_t cnt_bytes = al((size_t)batch * 16);
+        DBG_STEP("pinned block: reserve");
         rc = imatch_hs_reserve(ctx, cnt_bytes + (size_t)batch * kp_hint * sizeof(KpRec));
         if (rc) return rc;
+        DBG_STEP("pinned block reserved");
         int* h_cnt = (int*)ctx->hs;                              // [batch][4]
         KpRec* h_kp = (KpRec*)((char*)ctx->hs + cnt_bytes);      // [batch][kp_hint]
         // ends the record copy on the second stream on every way out of this attempt
@@ -1830,7 +1852,9 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         }
         const bool timing = getenv("IMATCH_TIMING") != nullptr;
         const double t_a = now_ms();
+        DBG_STEP("chain queued: sync for the counts");
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        DBG_STEP("counts are here");
         const double t_b = now_ms();
         int max_cand = 0, max_ref = 0, max_kp = 0;
         for (int b = 0; b < batch; ++b) {
@@ -1868,6 +1892,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             }
         }
         if (refetch || max_fetch > kp_hint) {  // the guess was short: fetch everything again at the right width
+            DBG_STEP("records: second fetch");
             HIP_TRY(ctx, rec_copy.wait());
             kp_hint = std::max(kp_hint, max_fetch);
             rc = imatch_hs_reserve(ctx, cnt_bytes + (size_t)batch * kp_hint * sizeof(KpRec));  // may move hs
@@ -1988,6 +2013,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // the host copy of the keypoint table is written while the GPU works on the descriptors (it reads the pinned rows
         // the upload queued above is reading too)
         {
+            DBG_STEP("descriptors queued: wait for the record copy");
             const hipError_t e = rec_copy.wait();
             if (e != hipSuccess) { imatch_features_free(f); return imatch_set_err(ctx, IMATCH_EHIP, "record copy: %s", hipGetErrorString(e)); }
         }
@@ -1995,6 +2021,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         else
             for (int b = 0; b < batch; ++b) fill_table(b);
         *out = f;
+        DBG_STEP("leave");
         return IMATCH_OK;
     }
     return imatch_set_err(ctx, IMATCH_ESIZE, "keypoint lists kept overflowing");
