@@ -437,10 +437,12 @@ knn2_kernel8(const uint4* __restrict__ Qd, const uint4* __restrict__ Td, const i
             b2[qb] = l_second ? l1 : w2; i2[qb] = l_second ? li1 : wi2;
         }
     }
-    if (q == 0) {
+    // (the lane's place recomputed here: kept in a register across the stage loop it was the one value the allocator spilled)
+    const unsigned lz = lane_now();
+    if ((lz >> 4) == 0) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            const int64_t o = (int64_t)(list0 + chunk) * Qpad + qrow0 + qb * 16 + r;
+            const int64_t o = (int64_t)(list0 + chunk) * Qpad + qrow0 + qb * 16 + (int)(lz & 15u);
             pb[o] = make_int2(b1[qb], b2[qb]);
             pi[o] = make_int2(i1[qb], i2[qb]);
         }
