@@ -55,6 +55,9 @@ struct imatch_akaze_state {
     float* cand;             // device [cap][AK_CAND_FLOATS]; its own allocation, grown when a scan overflows it
     int cand_cap;
     int cand_hint;           // candidates of the previous call + a margin: how many records the first download takes
+    int early_hint;          // the same for the candidates of the early levels (see akaze_run)
+    hipStream_t side;        // default priority; the early levels' response and candidates run here beside the small levels
+    hipEvent_t ev_fork, ev_early;
     float* kp_dev;           // device [kp_cap][8]: x, y, size, angle, response, octave, level, pad; own allocation
     float* desc_dev;         // device [kp_cap][64], behind kp_dev
     int kp_cap;
@@ -68,6 +71,12 @@ void imatch_akaze_state_free(imatch_ctx* ctx) {
     if (ctx->akaze->arena) (void)hipFree(ctx->akaze->arena);
     if (ctx->akaze->cand) (void)hipFree(ctx->akaze->cand);
     if (ctx->akaze->kp_dev) (void)hipFree(ctx->akaze->kp_dev);
+    if (ctx->akaze->side) {
+        (void)hipStreamSynchronize(ctx->akaze->side);
+        (void)hipStreamDestroy(ctx->akaze->side);
+        (void)hipEventDestroy(ctx->akaze->ev_fork);
+        (void)hipEventDestroy(ctx->akaze->ev_early);
+    }
     delete ctx->akaze;
     ctx->akaze = nullptr;
 }
@@ -537,10 +546,10 @@ __device__ __forceinline__ void ak_deriv_taps(int s, ak_taps& kd, ak_taps& ks) {
 
 // Lx = D_x(Lsmooth), Ly = D_y(Lsmooth) (sepFilter2D, BORDER_REFLECT_101)
 __global__ void __launch_bounds__(256)
-ak_deriv1_kernel(ak_levels_all L) {
+ak_deriv1_kernel(ak_levels_all L, int z0) {
     __shared__ float in[AK_IN_H][AK_IN_W];
     __shared__ float tmp[AK_IN_H][AK_TW + 1];
-    const int lv = blockIdx.z;
+    const int lv = blockIdx.z + z0;
     const int rows = L.rows[lv], cols = L.cols[lv], s = L.s[lv];
     const int x0 = blockIdx.x * AK_TW, y0 = blockIdx.y * AK_TH;
     if (x0 >= cols || y0 >= rows) return;
@@ -567,10 +576,10 @@ ak_deriv1_kernel(ak_levels_all L) {
 
 // Ldet = (D_x(Lx) D_y(Ly) - D_y(Lx)^2) s^4
 __global__ void __launch_bounds__(256)
-ak_det_kernel(ak_levels_all L) {
+ak_det_kernel(ak_levels_all L, int z0) {
     __shared__ float in[AK_IN_H][AK_IN_W];
     __shared__ float tmp[AK_IN_H][AK_TW + 1];
-    const int lv = blockIdx.z;
+    const int lv = blockIdx.z + z0;
     const int rows = L.rows[lv], cols = L.cols[lv], s = L.s[lv];
     const int x0 = blockIdx.x * AK_TW, y0 = blockIdx.y * AK_TH;
     if (x0 >= cols || y0 >= rows) return;
@@ -606,9 +615,9 @@ ak_det_kernel(ak_levels_all L) {
 // atomics on the single counter complete at about one per 20 ns, and a launch finds tens of thousands of candidates.
 #define AK_CAND_ROWS 8
 __global__ void __launch_bounds__(256)
-ak_candidates_kernel(ak_levels_all L, float thr, int* __restrict__ n_cand, float* __restrict__ cand, int cap) {
+ak_candidates_kernel(ak_levels_all L, int z0, float thr, int* __restrict__ n_cand, float* __restrict__ cand, int cap) {
     __shared__ int blk_count, blk_base;
-    const int level = blockIdx.z;
+    const int level = blockIdx.z + z0;
     const int rows = L.rows[level], cols = L.cols[level], border = L.border[level];
     const float* __restrict__ Ldet = L.Ldet[level];
     if (border + 1 >= rows) return;   // "if border is too big we shouldn't search any keypoints" (uniform per block)
@@ -843,6 +852,7 @@ static int akaze_prepare(imatch_ctx* ctx, int h, int w, int omax, int nsub) {
     S = new (std::nothrow) imatch_akaze_state();
     if (!S) return imatch_set_err(ctx, IMATCH_ENOMEM, "host allocation failed");
     S->arena = nullptr; S->cand = nullptr; S->kp_dev = nullptr; S->desc_dev = nullptr; S->n_levels = 0; S->n_kp = 0;
+    S->side = nullptr; S->ev_fork = nullptr; S->ev_early = nullptr; S->early_hint = 0;
     ctx->akaze = S;
     S->h = h; S->w = w; S->omax = omax; S->nsub = nsub;
     const float soffset = 1.6f, derivative_factor = 1.5f, smax = 12.0f * sqrtf(2.0f);
@@ -1014,6 +1024,54 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
         hipLaunchKernelGGL(ak_kc_kernel, dim3(1), dim3(64), 0, st, S->hist, S->hmax, 300, total, 0.7f, P->n_octaves, S->kc);
     }
     static const bool small_pairs = !(getenv("IMATCH_AKAZE_PAIRS") && atoi(getenv("IMATCH_AKAZE_PAIRS")) == 0);   // A/B runs
+    // The response / candidate launches take a range of levels (blockIdx.z + z0 = level)
+    ak_levels_all LA;
+    {
+        LA.n = S->n_levels;
+        for (int i = 0; i < AK_MAX_LEVELS; ++i) {
+            const ak_level* e = &S->lv[i < S->n_levels ? i : 0];
+            LA.rows[i] = e->rows; LA.cols[i] = e->cols; LA.s[i] = e->sigma_size; LA.border[i] = e->border;
+            LA.Lsmooth[i] = e->Lsmooth; LA.Lx[i] = e->Lx; LA.Ly[i] = e->Ly; LA.Ldet[i] = e->Ldet;
+        }
+    }
+    auto launch_group = [&](hipStream_t sq, int z0, int z1) {
+        int max_rows = 1, max_cols = 1, max_iw = 0, max_ih = 0;
+        for (int i = z0; i < z1; ++i) {
+            const ak_level* e = &S->lv[i];
+            max_rows = std::max(max_rows, e->rows); max_cols = std::max(max_cols, e->cols);
+            max_iw = std::max(max_iw, e->cols - 2 * e->border); max_ih = std::max(max_ih, e->rows - 2 * e->border);
+        }
+        const dim3 g((max_cols + AK_TW - 1) / AK_TW, (max_rows + AK_TH - 1) / AK_TH, z1 - z0);
+        hipLaunchKernelGGL(ak_deriv1_kernel, g, dim3(256), 0, sq, LA, z0);
+        hipLaunchKernelGGL(ak_det_kernel, g, dim3(256), 0, sq, LA, z0);
+        if (max_iw > 0 && max_ih > 0)
+            hipLaunchKernelGGL(ak_candidates_kernel, dim3((max_iw + 63) / 64, (max_ih + 4 * AK_CAND_ROWS - 1) / (4 * AK_CAND_ROWS), z1 - z0), dim3(256), 0, sq, LA,
+                               z0, (float)P->threshold, S->n_cand, S->cand, S->cand_cap);
+    };
+    auto is_small = [&](int i) {
+        const ak_level* e = &S->lv[i];
+        return e->rows * e->cols <= AK_SMALL_PX && 2 * e->rows * e->cols + 4 * e->cols <= AK_SMALL_LDS_FLOATS && e->rows >= 2 && e->cols >= 2;
+    };
+    // A frame's host time is mostly the candidate filter (0.3 ms), and the last ten levels are single-workgroup launches
+    // that leave the chip empty (0.5 ms): the levels BEFORE the first of those ("early") get their response and candidates
+    // on a second stream while that chain runs, and the host filters them meanwhile. IMATCH_AKAZE_OVERLAP=0: one stream.
+    static const bool overlap_env = !(getenv("IMATCH_AKAZE_OVERLAP") && atoi(getenv("IMATCH_AKAZE_OVERLAP")) == 0);
+    int first_small = S->n_levels;
+    for (int i = 1; i < S->n_levels; ++i)
+        if (is_small(i)) { first_small = i; break; }
+    const bool overlap = overlap_env && first_small >= 2 && first_small < S->n_levels;
+    if (overlap && !S->side) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&S->side, hipStreamNonBlocking));   // default priority (see sift.hip on why)
+        HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_early, hipEventDisableTiming));
+    }
+    // pinned block: [early count | total count] [early records (a guess)] [all records (a guess)]
+    const int guessE = overlap ? std::min(S->cand_cap, S->early_hint > 0 ? S->early_hint : 8192) : 0;
+    const int guess = std::min(S->cand_cap, S->cand_hint > 0 ? S->cand_hint : 8192);
+    const size_t cnt_b = 256, guessE_b = (size_t)guessE * AK_CAND_FLOATS * 4, guess_b = (size_t)guess * AK_CAND_FLOATS * 4;
+    rc = imatch_hs_reserve(ctx, cnt_b + guessE_b + guess_b);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(S->n_cand, 0, 4, st));
     for (int i = 1; i < S->n_levels; ++i) {
         ak_level* e = &S->lv[i];
         ak_level* p = &S->lv[i - 1];
@@ -1022,6 +1080,18 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
         // resize(): scale = 1 / (dsize / ssize) per axis; the 2 x 2 box path when both are exactly 2
         const double sc_x = 1. / ((double)e->cols / p->cols), sc_y = 1. / ((double)e->rows / p->rows);
         const int fast = fabs(sc_x - 2.0) < 2.220446049250313e-16 && fabs(sc_y - 2.0) < 2.220446049250313e-16;
+        if (overlap && i == first_small) {
+            // Fork: the levels before this one are complete. Their response, candidates and the candidates' way to the host
+            // go to the second stream, beside the chain of single-workgroup levels that starts here; the host filters them
+            // while that chain runs (below).
+            HIP_TRY(ctx, hipEventRecord(S->ev_fork, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(S->side, S->ev_fork, 0));
+            launch_group(S->side, 0, first_small);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->hs, S->n_cand, 4, hipMemcpyDeviceToHost, S->side));
+            HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->hs + cnt_b, S->cand, guessE_b, hipMemcpyDeviceToHost, S->side));
+            HIP_TRY(ctx, hipEventRecord(S->ev_early, S->side));
+        }
         if (e->rows * e->cols <= AK_SMALL_PX && 2 * e->rows * e->cols + 4 * e->cols <= AK_SMALL_LDS_FLOATS && e->rows >= 2 &&
             e->cols >= 2) {
             if ((e->cols & 1) == 0 && small_pairs)
@@ -1059,61 +1129,81 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
             cur = o;
         }
     }
-    // A3 + candidates
-    ak_levels_all LA;
-    int max_iw = 0, max_ih = 0;
-    {
-        LA.n = S->n_levels;
-        int max_rows = 1, max_cols = 1;
-        for (int i = 0; i < AK_MAX_LEVELS; ++i) {
-            const bool ok = i < S->n_levels;
-            const ak_level* e = &S->lv[ok ? i : 0];
-            LA.rows[i] = e->rows; LA.cols[i] = e->cols; LA.s[i] = e->sigma_size; LA.border[i] = e->border;
-            LA.Lsmooth[i] = e->Lsmooth; LA.Lx[i] = e->Lx; LA.Ly[i] = e->Ly; LA.Ldet[i] = e->Ldet;
-            if (ok) {
-                max_rows = std::max(max_rows, e->rows); max_cols = std::max(max_cols, e->cols);
-                max_iw = std::max(max_iw, e->cols - 2 * e->border); max_ih = std::max(max_ih, e->rows - 2 * e->border);
-            }
-        }
-        const dim3 g((max_cols + AK_TW - 1) / AK_TW, (max_rows + AK_TH - 1) / AK_TH, S->n_levels);
-        hipLaunchKernelGGL(ak_deriv1_kernel, g, dim3(256), 0, st, LA);
-        hipLaunchKernelGGL(ak_det_kernel, g, dim3(256), 0, st, LA);
+    // A3 + candidates of the other levels (of all levels without the overlap)
+    if (overlap) {
+        HIP_TRY(ctx, hipStreamWaitEvent(st, S->ev_early, 0));   // the early records are the first ones of the list: nothing is appended before they are counted
+        launch_group(st, first_small, S->n_levels);
+    } else {
+        launch_group(st, 0, S->n_levels);
     }
-    auto scan = [&]() -> int {
-        HIP_TRY(ctx, hipMemsetAsync(S->n_cand, 0, 4, st));
-        if (max_iw > 0 && max_ih > 0)
-            hipLaunchKernelGGL(ak_candidates_kernel, dim3((max_iw + 63) / 64, (max_ih + 4 * AK_CAND_ROWS - 1) / (4 * AK_CAND_ROWS), S->n_levels), dim3(256), 0, st, LA,
-                               (float)P->threshold, S->n_cand, S->cand, S->cand_cap);
-        HIP_TRY(ctx, hipGetLastError());
-        return IMATCH_OK;
-    };
-    rc = scan();
-    if (rc) return rc;
+    HIP_TRY(ctx, hipGetLastError());
     static const bool timing = getenv("IMATCH_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
-    const auto t_enq = now();
     // candidates -> host
     // (the count and a guess of the records -- the previous call's count plus a margin -- in ONE synchronisation; the rest,
     // if the guess was short, in a second one)
+    HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->hs + 64, S->n_cand, 4, hipMemcpyDeviceToHost, st));
+    if (guess) HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->hs + cnt_b + guessE_b, S->cand, guess_b, hipMemcpyDeviceToHost, st));
+    const auto t_enq = now();
+    std::vector<ak_level_pts> LP((size_t)S->n_levels);
+    // levels in parallel on the context's worker pool; even a frame's 6 k candidates gain (0.77 -> 0.41 ms), so the
+    // inline path is only a measurement aid (IMATCH_AKAZE_PAR_MIN = candidate count below which it is taken)
+    static const int par_min = getenv("IMATCH_AKAZE_PAR_MIN") ? atoi(getenv("IMATCH_AKAZE_PAR_MIN")) : 0;
     int n_cand = 0;
-    const int guess = std::min(S->cand_cap, S->cand_hint > 0 ? S->cand_hint : 8192);
-    const size_t cnt_b = 256, guess_b = (size_t)guess * AK_CAND_FLOATS * 4;
-    rc = imatch_hs_reserve(ctx, cnt_b + guess_b);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs, S->n_cand, 4, hipMemcpyDeviceToHost, st));
-    if (guess) HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->hs + cnt_b, S->cand, guess_b, hipMemcpyDeviceToHost, st));
+    auto pfor = [&](int cnt, const std::function<void(int)>& fn) {
+        if (n_cand < par_min) for (int i = 0; i < cnt; ++i) fn(i);
+        else imatch_parallel_for(ctx, cnt, fn);
+    };
+    // same level: row-major scan, the first kept neighbour decides (levels are independent of one another here);
+    // record numbers grouped by level (one counting pass), so that a level's task touches its own records only
+    auto same_level = [&](const float* raw, int n_rec, int l0, int l1) {
+        std::vector<int> lvl_start((size_t)S->n_levels + 1, 0), lvl_ids((size_t)n_rec);
+        for (int i = 0; i < n_rec; ++i) lvl_start[(int)raw[(size_t)i * AK_CAND_FLOATS] + 1]++;
+        for (int l = 0; l < S->n_levels; ++l) lvl_start[l + 1] += lvl_start[l];
+        {
+            std::vector<int> fill(lvl_start.begin(), lvl_start.end() - 1);
+            for (int i = 0; i < n_rec; ++i) lvl_ids[fill[(int)raw[(size_t)i * AK_CAND_FLOATS]]++] = i;
+        }
+        pfor(l1 - l0, [&](int k) {
+            const int l = l0 + k;
+            ak_level_pts& P = LP[l];
+            bucket_level(raw, lvl_ids.data() + lvl_start[l], lvl_start[l + 1] - lvl_start[l], S->lv[l].rows, P);
+            const int r = S->lv[l].sigma_size;
+            for (int p = 0; p < (int)P.x.size(); ++p) {
+                const int nb = P.find(P.x[p], P.y[p], r);
+                if (nb >= 0) {
+                    if (P.v[(size_t)p * 9 + 4] > P.v[(size_t)nb * 9 + 4]) P.alive[nb] = 0;
+                    else continue;
+                }
+                P.alive[p] = 1;
+            }
+        });
+    };
+    bool early_done = false;
+    if (overlap) {   // the early levels' candidates are here long before the chain of small levels ends
+        HIP_TRY(ctx, hipEventSynchronize(S->ev_early));
+        const int nE = *(const int*)ctx->hs;
+        S->early_hint = nE + nE / 4 + 256;
+        if (nE <= guessE && nE <= S->cand_cap) {
+            n_cand = nE;   // (pfor's threshold)
+            same_level((const float*)((char*)ctx->hs + cnt_b), nE, 0, first_small);
+            early_done = true;
+        }
+    }
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    n_cand = *(const int*)ctx->hs;
+    n_cand = *(const int*)((char*)ctx->hs + 64);
     bool have_guess = true;
     if (n_cand > S->cand_cap) {
         have_guess = false;   // the scan counted them all: grow the list and scan again (the planes are still there)
+        early_done = false;
         rc = akaze_grow_lists(ctx, n_cand + n_cand / 8, 0);
         if (rc) return rc;
-        rc = scan();
-        if (rc) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(S->n_cand, 0, 4, st));
+        launch_group(st, 0, S->n_levels);
+        HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(&n_cand, S->n_cand, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         if (n_cand > S->cand_cap) return imatch_set_err(ctx, IMATCH_ESIZE, "AKAZE: candidate list overflow");
@@ -1123,45 +1213,23 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     S->cand_hint = n_cand + n_cand / 4 + 256;
     if (n_cand) {
         const size_t rb = (size_t)n_cand * AK_CAND_FLOATS * 4;
-        if (!have_guess || n_cand > guess) {   // everything again at the right width (the block may move)
+        size_t at = cnt_b + guessE_b;
+        if (!have_guess || n_cand > guess) {   // everything again at the right width (the block may move: the early levels are built already)
             rc = imatch_hs_reserve(ctx, cnt_b + rb);
             if (rc) return rc;
-            HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->hs + cnt_b, S->cand, rb, hipMemcpyDeviceToHost, st));
+            at = cnt_b;
+            HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->hs + at, S->cand, rb, hipMemcpyDeviceToHost, st));
             HIP_TRY(ctx, hipStreamSynchronize(st));
         }
-        raw = (const float*)((char*)ctx->hs + cnt_b);
+        raw = (const float*)((char*)ctx->hs + at);
     }
     const auto t_dl = now();
-    std::vector<ak_level_pts> LP((size_t)S->n_levels);
-    // levels in parallel on the context's worker pool; even a frame's 6 k candidates gain (0.77 -> 0.41 ms), so the
-    // inline path is only a measurement aid (IMATCH_AKAZE_PAR_MIN = candidate count below which it is taken)
-    static const int par_min = getenv("IMATCH_AKAZE_PAR_MIN") ? atoi(getenv("IMATCH_AKAZE_PAR_MIN")) : 0;
-    auto pfor = [&](int cnt, const std::function<void(int)>& fn) {
-        if (n_cand < par_min) for (int i = 0; i < cnt; ++i) fn(i);
-        else imatch_parallel_for(ctx, cnt, fn);
-    };
-    // same level: row-major scan, the first kept neighbour decides (levels are independent of one another here)
-    // record numbers grouped by level (one counting pass), so that a level's task touches its own records only
-    std::vector<int> lvl_start((size_t)S->n_levels + 1, 0), lvl_ids((size_t)n_cand);
-    for (int i = 0; i < n_cand; ++i) lvl_start[(int)raw[(size_t)i * AK_CAND_FLOATS] + 1]++;
-    for (int l = 0; l < S->n_levels; ++l) lvl_start[l + 1] += lvl_start[l];
-    {
-        std::vector<int> fill(lvl_start.begin(), lvl_start.end() - 1);
-        for (int i = 0; i < n_cand; ++i) lvl_ids[fill[(int)raw[(size_t)i * AK_CAND_FLOATS]]++] = i;
+    if (early_done) {
+        same_level(raw, n_cand, first_small, S->n_levels);   // the early levels are built already
+    } else {
+        for (auto& P : LP) P = ak_level_pts();
+        same_level(raw, n_cand, 0, S->n_levels);
     }
-    pfor(S->n_levels, [&](int l) {
-        ak_level_pts& P = LP[l];
-        bucket_level(raw, lvl_ids.data() + lvl_start[l], lvl_start[l + 1] - lvl_start[l], S->lv[l].rows, P);
-        const int r = S->lv[l].sigma_size;
-        for (int p = 0; p < (int)P.x.size(); ++p) {
-            const int nb = P.find(P.x[p], P.y[p], r);
-            if (nb >= 0) {
-                if (P.v[(size_t)p * 9 + 4] > P.v[(size_t)nb * 9 + 4]) P.alive[nb] = 0;
-                else continue;
-            }
-            P.alive[p] = 1;
-        }
-    });
     // Against the level below, then against the level above. OpenCV runs the level pairs one after the other, but pair
     // (l, l-1) only READS level l's flags as the phase before left them (the pass that changes them comes later) and is
     // the only one that WRITES level l-1's: with a snapshot of the flags per phase the pairs are independent.
