@@ -782,18 +782,20 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     const int nQt = (int)((q->n + qtile - 1) / qtile);
     const int nStagesAll = (int)(t->n_pad / TNs);
     const int slots = 512;
-    // chunks of a range of stages: a multiple of 8 (one group per XCD); about two workgroups per CU slot; >= 4 stages each
+    // chunks of a range of stages: a multiple of 8 (one group per XCD); two rounds of 512 workgroup slots (large form) or one of 768 (a frame's forms); >= 4 stages each
     auto pick_chunks = [&](int nStages) {
         // (rounded DOWN to a multiple of 8, so that the grid stays within two rounds of slots)
         // -- ONE round for the frame forms: their launches are short (a frame against a map of well under a million
         // rows), a second, partly filled round would be a large part of them (1500 x 59k: 54 -> 44 us, 2951 x 59k: 76 -> 67)
         const bool one_round = small || short8;
-        int c = (((one_round ? 1 : 2) * slots + (one_round ? 0 : nQt - 1)) / nQt / 8) * 8;
+        // (three workgroups fit a CU since the int8 form: the single round is 768 slots; the two-round rule of the large
+        // form keeps its 2 x 512 -- more, shorter chunks were measured and lose there)
+        int c = ((one_round ? slots + slots / 2 : 2 * slots + nQt - 1) / nQt / 8) * 8;
         // ... and chunks of at most 16k rows (2 MB, half an XCD's L2): the query tiles that share a chunk then
         // re-read it from L2 however far apart they run, and the many short workgroups balance the tail
         c = std::max(c, (int)(((int64_t)nStages * TNs + 16383) / 16384 + 7) / 8 * 8);
         c = std::min(c, 256);
-        if (c > nStages / 4) c = (nStages / 4 / 8) * 8;
+        if (c > nStages / 4) c = (nStages / 4 / 8) * 8;   // (six stages at least were tried: 700 x 20 k 0.023 -> 0.033 ms)
         if (c < 8) c = 8;
         if (const char* e = getenv("IMATCH_KNN_CHUNKS")) c = std::max(8, atoi(e) / 8 * 8);  // tuning override
         return c;
