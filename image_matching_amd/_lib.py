@@ -7,7 +7,9 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libimatch.so")
+# IMATCH_LIB: another build of the library (development builds made with IMATCH_LIB_OUT / IMATCH_BUILD_DEFINES, see
+# build.py); the product is the in-tree libimatch.so
+_LIB_PATH = os.environ.get("IMATCH_LIB") or os.path.join(_HERE, "libimatch.so")
 _lib = None
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -112,11 +114,13 @@ SIGNATURES = {
     "imatch_sift_debug_layer": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
                                                ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "imatch_sift_debug_octaves": (ctypes.c_int, [c_vp]),
+    "imatch_sift_debug_layer_rows": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p]),
     "imatch_homography": (ctypes.c_int, [c_vp, c_f32p, c_f32p, ctypes.c_int, ctypes.c_double, ctypes.c_uint64,
                                          ctypes.POINTER(ctypes.c_double), c_u8p, ctypes.POINTER(ctypes.c_int)]),
     "imatch_knn2": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32p, c_f32p]),
     "imatch_knn2_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
     "imatch_knn2_noalloc_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
+    "imatch_knn2_debug_last_chunks": (ctypes.c_int, [c_vp]),
     "imatch_merge_top2_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, c_vp]),
     "imatch_ratio_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_double, c_i32p, c_i32p, c_f32p,
                                         ctypes.POINTER(c_i64)]),
@@ -150,6 +154,28 @@ def load_library():
 
 def _ptr(a, t):
     return a.ctypes.data_as(t)
+
+
+def _clip_segment(x0, y0, x1, y1, box):
+    """Liang-Barsky on Python integers (exact): the part of the segment inside [-box, box]^2 with end points rounded to
+    the nearest integer, or None if it misses the box."""
+    from fractions import Fraction
+    t0, t1 = Fraction(0), Fraction(1)
+    dx, dy = x1 - x0, y1 - y0
+    for p, q in ((-dx, x0 + box), (dx, box - x0), (-dy, y0 + box), (dy, box - y0)):
+        if p == 0:
+            if q < 0:
+                return None
+            continue
+        r = Fraction(q, p)
+        if p < 0:
+            t0 = max(t0, r)
+        else:
+            t1 = min(t1, r)
+    if t0 > t1:
+        return None
+    rnd = lambda v: int(round(v))
+    return rnd(x0 + t0 * dx), rnd(y0 + t0 * dy), rnd(x0 + t1 * dx), rnd(y0 + t1 * dy)
 
 
 class Features:
@@ -431,12 +457,21 @@ class Context:
         for i, p in enumerate(prims):
             c = p[3]
             c = (list(c) + [0, 0, 0, 0])[:4] if np.ndim(c) else [c, 0, 0, 0]     # cv2: a scalar colour is Scalar(v, 0, 0, 0)
-            lim = 1 << 20     # far-off coordinates (a wild homography) are clipped as cv2 clips them, not refused
-            x0, y0 = (int(min(max(v, -lim), lim)) for v in p[1])
+            lim = 1 << 28     # the library's coordinate limit
+            x0, y0 = (int(v) for v in p[1])
             if p[0] == "line":
-                x1, y1 = (int(min(max(v, -lim), lim)) for v in p[2])
+                x1, y1 = (int(v) for v in p[2])
+                if max(abs(x0), abs(y0), abs(x1), abs(y1)) > lim:
+                    # a wild homography: the SEGMENT is clipped (exact integer arithmetic, as cv2.clipLine clips it) to a
+                    # box far outside any image, so its direction stays what it was; clamping the end points one by one
+                    # would turn the line
+                    seg = _clip_segment(x0, y0, x1, y1, 1 << 24)
+                    if seg is None:
+                        seg = (lim, lim, lim, lim)       # nowhere near the image: a point that is dropped
+                    x0, y0, x1, y1 = seg
                 rec[i, :6] = (0, x0, y0, x1, y1, p[4])
             elif p[0] == "circle":
+                x0, y0 = (min(max(v, -lim), lim) for v in (x0, y0))     # a circle that far away touches no image
                 rec[i, :6] = (1, x0, y0, p[2], 0, p[4])
             else:
                 raise ValueError("unknown primitive %r" % (p[0],))
@@ -569,6 +604,15 @@ class Context:
                                                          ctypes.byref(c)))
         return out
 
+    def sift_debug_layer_rows(self, o, i, row0, nrows):
+        """Rows [row0, row0 + nrows) of Gaussian layer i of octave o of the last extraction (test hook)."""
+        r, c = ctypes.c_int(), ctypes.c_int()
+        with self.lock:
+            self._check(self.lib.imatch_sift_debug_layer(self._h, 0, int(o), int(i), None, ctypes.byref(r), ctypes.byref(c)))
+            out = np.empty((int(nrows), c.value), np.float32)
+            self._check(self.lib.imatch_sift_debug_layer_rows(self._h, int(o), int(i), int(row0), int(nrows), _ptr(out, c_f32p)))
+        return out
+
     def sift_debug_octaves(self):
         return self.lib.imatch_sift_debug_octaves(self._h)
 
@@ -630,6 +674,10 @@ class Context:
         """knn2_dev with the scratch in the library's fixed per-GPU block: no allocation (imatch_knn2_noalloc_dev)."""
         with self.lock:
             self._check(self.lib.imatch_knn2_noalloc_dev(self._h, q._h, t._h, int(idx_offset), c_vp(out4_ptr)))
+
+    def knn2_last_chunks(self):
+        """Train chunks of this context's last kNN launch (test hook)."""
+        return int(self.lib.imatch_knn2_debug_last_chunks(self._h))
 
     def merge_top2_dev(self, in4_ptr, n_lists, nq, out4_ptr):
         with self.lock:

@@ -28,6 +28,7 @@ struct imatch_ctx {
     int prof;
     hipEvent_t ev0, ev1;   // kNN MFMA kernel
     hipEvent_t ev2, ev3;   // SIFT scale-space stage (upsample .. last extrema scan)
+    int knn_last_chunks;   // train chunks of the last kNN launch (imatch_knn2_debug_last_chunks)
     // SIFT pyramid arena of the last extraction (kept for reuse by the next frame of the same size)
     struct imatch_sift_state* sift;
     struct imatch_workers* workers;   // host worker pool, created on first use

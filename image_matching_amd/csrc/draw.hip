@@ -85,9 +85,32 @@ overlay_owner_kernel(const imatch_draw_prim* __restrict__ prims, int n, int H, i
         const int dx = p.x1 - p.x0, dy = p.y1 - p.y0;
         const int m = max(abs(dx), abs(dy));
         const int hb = t / 2, S = 2 * hb + 1, SS = S * S;
-        const long long total = (long long)(m + 1) * SS;
+        // Only the DDA steps whose brush can touch the image are walked: step k sits at x0 + round(k dx / m), so
+        // k dx / m within [-hb - x0 - 1, W - 1 + hb - x0 + 1] is a superset of the steps that matter on the x axis (the
+        // rounding moves a step by at most half a pixel), likewise on y; the axis with |d| = m makes the intersection at
+        // most max(W, H) + 2 hb + 3 steps long, whatever the end points (a wild homography puts them millions of pixels
+        // away: walking all m + 1 steps on one wave took minutes). Steps outside the range only produce pixels that
+        // put() would drop, so the drawn pixels are the same.
+        long long k_lo = 0, k_hi = m;
+        auto clip_axis = [&](int p0, int d, int extent) {
+            const long long lo = -(long long)hb - p0 - 1, hi = (long long)extent - 1 + hb - p0 + 1;   // bounds on k d / m
+            if (d == 0 || m == 0) {
+                if (0 < lo || 0 > hi) k_hi = -1;
+                return;
+            }
+            // k d in [lo m, hi m]
+            const long long a = lo * m, b = hi * m;
+            auto fdiv = [](long long n, long long q) { long long r = n / q; if ((n % q != 0) && ((n < 0) != (q < 0))) --r; return r; };
+            auto cdiv = [&](long long n, long long q) { return -fdiv(-n, q); };
+            const long long ka = d > 0 ? cdiv(a, d) : cdiv(b, d), kb = d > 0 ? fdiv(b, d) : fdiv(a, d);
+            k_lo = max(k_lo, ka);
+            k_hi = min(k_hi, kb);
+        };
+        clip_axis(p.x0, dx, W);
+        clip_axis(p.y0, dy, H);
+        const long long total = k_hi >= k_lo ? (k_hi - k_lo + 1) * SS : 0;
         for (long long e = lane; e < total; e += 64) {
-            const int k = (int)(e / SS), c = (int)(e % SS), u = c % S - hb, v = c / S - hb;
+            const int k = (int)(k_lo + e / SS), c = (int)(e % SS), u = c % S - hb, v = c / S - hb;
             if (4 * (u * u + v * v) <= t * t)
                 put(owner, H, W, p.x0 + (m ? dda(k, dx, m) : 0) + u, p.y0 + (m ? dda(k, dy, m) : 0) + v, i);
         }
@@ -123,12 +146,12 @@ extern "C" int imatch_draw_overlay(imatch_ctx* ctx, const uint8_t* img, int h, i
         return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
     for (int i = 0; i < n; ++i) {
         const imatch_draw_prim& p = prims[i];
-        const int lim = 1 << 20;
+        const int lim = 1 << 28;   // (the kernel's 64-bit products of a step number and a difference stay below 2^60)
         bool ok = (p.kind == IMATCH_DRAW_LINE || p.kind == IMATCH_DRAW_CIRCLE) && abs(p.x0) <= lim && abs(p.y0) <= lim &&
                   p.thickness <= 255;
         if (ok && p.kind == IMATCH_DRAW_LINE) ok = abs(p.x1) <= lim && abs(p.y1) <= lim && p.thickness >= 1;
         if (ok && p.kind == IMATCH_DRAW_CIRCLE) ok = p.x1 >= 0 && p.x1 <= 4096 && p.thickness != 0;
-        if (!ok) return imatch_set_err(ctx, IMATCH_EINVAL, "primitive %d: kind, coordinates (|v| <= 2^20), radius (<= 4096) or "
+        if (!ok) return imatch_set_err(ctx, IMATCH_EINVAL, "primitive %d: kind, coordinates (|v| <= 2^28), radius (<= 4096) or "
                                        "thickness (1..255; circles also < 0 = filled) out of range", i);
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));

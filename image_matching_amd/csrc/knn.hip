@@ -813,6 +813,7 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
         if ((size_t)nChunks > room) nChunks = (int)(room / 8) * 8;
     }
     const int64_t nLists = nChunks;   // the kernel merges its four row quarters itself: one list per chunk
+    ctx->knn_last_chunks = nChunks;
     const size_t pbytes = (size_t)nLists * Qpad * 8;
     if (!ws) {
         int rc = imatch_ws_reserve(ctx, 2 * pbytes + gbytes);
@@ -935,6 +936,8 @@ int imatch_knn2_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
                     int32_t* out4_dev) {
     return knn2_run(ctx, q, t, idx_offset, out4_dev);
 }
+
+int imatch_knn2_debug_last_chunks(imatch_ctx* ctx) { return ctx ? ctx->knn_last_chunks : 0; }
 
 int imatch_knn2_noalloc_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, int32_t idx_offset,
                             int32_t* out4_dev) {

@@ -85,6 +85,8 @@ struct imatch_sift_state {
     // the host needs only the counters to launch it, the records for the keypoint table it fills afterwards.
     hipStream_t copy;
     hipEvent_t ev_sorted;
+    // the one-workgroup-per-octave form of the small-octave kernel once timed out on this context: it is not used again
+    bool no_tail_split;
 };
 
 void imatch_sift_state_free(imatch_ctx* ctx) {
@@ -622,7 +624,7 @@ extern "C" int imatch_dbg_tail_trace(long long* out) {
 template <int R1, int R2, int R3, int R4, int R5, bool SPLIT>
 __global__ void __launch_bounds__(1024)
 pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* __restrict__ cand, int cap,
-                         int* __restrict__ count, size_t zs) {
+                         int* __restrict__ count, size_t zs, int withhold) {
     const size_t zo = (size_t)blockIdx.z * zs;
     cand = ZP(cand); count = ZP(count);
     static_assert(R1 <= TF_M && R2 <= TF_M && R3 <= TF_M && R4 <= TF_M && R5 <= TF_M, "margin too small");
@@ -643,13 +645,18 @@ pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* _
         const int rows = T.rows[o], cols = T.cols[o], n = rows * cols, P = tf_pitch(cols);
         if (SPLIT && o > o_start) {
             if (tid == 0) {
-                // bounded (a few seconds): if the flag never comes -- the workgroup before this one never ran -- the candidate
-                // counter's sign bit is set, the kernels behind this one then find nothing to do and the host reports an error
-                // instead of waiting for ever
-                long long spins = 0;
+                // bounded (about a second; the whole kernel takes 70 us when nothing holds it up): if the flag never comes
+                // -- the workgroup before this one never ran -- the candidate counter's sign bit is set and the octave
+                // recorded (count[4] = octave + 1), the kernels behind this one then find nothing to do, and the host
+                // runs the extraction again with the one-workgroup walk, which waits for nobody
+                int spins = 0;
                 while (__hip_atomic_load(ready + (o - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > 4000000) { atomicOr(count, (int)0x80000000); break; }
+                    if (++spins > 1000000) {
+                        atomicOr(count, (int)0x80000000);
+                        atomicMax(count + 4, o + 1);
+                        break;
+                    }
                 }
             }
             __syncthreads();
@@ -738,7 +745,8 @@ pyramid_tail_fast_kernel(PyrTable T, int o_start, TailFK gk, float thr, uint2* _
             tf_col_pass<R3>(A, tm, gk.k[2], rows, cols, P, dg + 2 * TAIL_MAXPX, TG(o, 3), nullptr);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(ready + o, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (withhold: the test knob IMATCH_DEBUG_TAIL_WITHHOLD -- this octave's flag is never published)
+            if (tid == 0 && o != withhold) __hip_atomic_store(ready + o, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             tf_mirror<R4>(A, rows, cols, P);
             __syncthreads();
         } else {
@@ -1051,12 +1059,21 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
         // scalar registers (base made wave-uniform explicitly, else the compiler wraps every load in a waterfall loop), a
         // sample's four pixels are raw buffer loads at 32-bit byte offsets, one of them with an immediate
         // (readfirstlane returns int: both halves go through unsigned, or a low half with bit 31 set smears over the high one)
-        const unsigned long long img_bits = (unsigned long long)img;
+        // The resource starts at the first row the window can touch (row py - radius - 1), not at the layer's: a buffer
+        // resource counts bytes in 32 bits and a 32768^2 layer of a 16384^2 map is exactly 2^32 of them -- with the layer's
+        // base and size, num_records wrapped to 0 and every octave-0 descriptor of such a map was built from zeros (found
+        // by the full-size test of configs[3]'s map leg). The window's rows are at most (2 radius + 3) x cols x 4 bytes
+        // (15 MB for the widest layer), and the byte offsets below count from row_base.
+        const int row_base = max(py - radius - 1, 0);
+        const unsigned long long img_bits = (unsigned long long)(img + (size_t)row_base * (size_t)cols);
         const unsigned img_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)img_bits);
         const unsigned img_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(img_bits >> 32));
         void* const img_u = (void*)(((unsigned long long)img_hi << 32) | (unsigned long long)img_lo);
+        const unsigned long long bytes_left = (unsigned long long)(rows - row_base) * (unsigned long long)cols * 4ull;
         const __amdgpu_buffer_rsrc_t img_rs = __builtin_amdgcn_make_buffer_rsrc(
-            img_u, 0, __builtin_amdgcn_readfirstlane(rows * cols * 4), 0x00020000);
+            img_u, 0, __builtin_amdgcn_readfirstlane((int)(unsigned)(bytes_left > 0xffffffffull ? 0xffffffffull : bytes_left)),
+            0x00020000);
+        const int py_rel = py - row_base;
         const unsigned cols4 = (unsigned)cols * 4u;
         unsigned long long* const hp = hist[wave];
         auto accumulate = [&](unsigned ps) {
@@ -1066,7 +1083,7 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
             const float r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f;
             float cbin = c_rot + d / 2 - 0.5f;
-            const unsigned at = ((unsigned)(py + i) * (unsigned)cols + (unsigned)(px + j)) * 4u - 4u;   // bytes, pixel x - 1
+            const unsigned at = ((unsigned)(py_rel + i) * (unsigned)cols + (unsigned)(px + j)) * 4u - 4u;   // bytes from row_base, pixel x - 1
             const float dx = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(img_rs, (int)(at + 8u), 0, 0)) -
                              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(img_rs, (int)at, 0, 0));
             const float dy = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(img_rs, (int)(at + 4u - cols4), 0, 0)) -
@@ -1552,7 +1569,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
     int cap = (int)std::min<size_t>((size_t)brows * bcols / 8 + 16384, (size_t)1 << 28);
     const size_t o_cnt = take(256);
     const size_t fixed_end = off;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (int attempt = 0; attempt < 5; ++attempt) {
         off = fixed_end;
         const size_t o_cand = take((size_t)cap * sizeof(uint2));
         const size_t o_ref = take((size_t)cap * sizeof(RefinedKp));
@@ -1640,16 +1657,12 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if ((use_side || split) && !S->side) {
             // Default priority. (Rounds 1-2 created this stream at the highest priority so that the later octaves' small
             // launches would get CU slots beside octave 0's big kernels. With TWO processes on one GPU -- the rehearsal
-            // form of bench.py -- that deadlocked about one run in five: a rank's first extraction never finished, its
-            // queues stuck behind the other process's; forty runs without the priority were clean, and one process alone
-            // is no slower without it: bench 7896 against 7778 frames/s, a frame 0.66 against 0.71 ms, the 8192^2 map's
-            // scale space 6.65 against 6.44 ms. IMATCH_SIFT_SIDE_PRIO=1 brings the old behaviour back for measurements.)
-            int prio_least = 0, prio_greatest = 0;
+            // form of bench.py -- that deadlocked about one run in five: a rank's first extraction never finished; forty
+            // runs without the priority were clean, and one process alone is no slower without it. Which queue or
+            // kernel was stuck was never identified -- see DESIGN.md section 5 -- so the configuration is gone, knob
+            // included.)
             DBG_STEP("second stream: create");
-            HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-            static const int side_prio = getenv("IMATCH_SIFT_SIDE_PRIO") ? atoi(getenv("IMATCH_SIFT_SIDE_PRIO")) : 0;
-            if (side_prio) HIP_TRY(ctx, hipStreamCreateWithPriority(&S->side, hipStreamNonBlocking, prio_greatest));
-            else HIP_TRY(ctx, hipStreamCreateWithFlags(&S->side, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&S->side, hipStreamNonBlocking));
             HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming));
         }
@@ -1731,6 +1744,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if (split) {   // the small octaves follow layer nl of octave o_tail - 1 on the main stream; the scans join below
             st2 = ctx->stream;
         }
+        bool used_tail_split = false;
         hipStream_t st_tail = st2;   // o_tail >= 1: the tail needs layer nl of octave o_tail - 1, which precedes it on st2 (or the fork)
         bool tail_fast = o_tail < n_oct && nl == 3 &&
                          (size_t)tf_ext_rows(T.rows[o_tail]) * tf_pitch(T.cols[o_tail]) <= TF_EXT;
@@ -1755,12 +1769,21 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             }
             static const int tail_split_env = getenv("IMATCH_SIFT_TAILSPLIT") ? atoi(getenv("IMATCH_SIFT_TAILSPLIT")) : 1;
             const int n_tail = n_oct - o_tail;
-            if (tail_split_env && n_tail > 1 && n_tail <= 16 && batch * n_tail <= 32)
+            // One workgroup per octave only on a single frame's chain (split), where the kernel is a third of the scale
+            // space and little else runs: on maps and batches (use_side) it would wait beside octave 0's chip-filling
+            // kernels for CUs with 155 KB of free LDS, and gains nothing measurable there. Never again on a context
+            // where the hand-off once timed out.
+            used_tail_split = tail_split_env && !use_side && !S->no_tail_split && n_tail > 1 && n_tail <= 16 &&
+                              batch * n_tail <= 32;
+            // test knob (read on every call): the flag of this octave is never published, which forces the time-out path
+            const char* wh = getenv("IMATCH_DEBUG_TAIL_WITHHOLD");
+            const int withhold = wh ? o_tail + atoi(wh) : -1;
+            if (used_tail_split)
                 hipLaunchKernelGGL((pyramid_tail_fast_kernel<5, 6, 8, 10, 13, true>), dim3(n_tail, 1, batch), dim3(1024),
-                                   TF_LDS_BYTES, st_tail, T, o_tail, tfk, thr, d_cand, cap, d_cnt, zs);
+                                   TF_LDS_BYTES, st_tail, T, o_tail, tfk, thr, d_cand, cap, d_cnt, zs, withhold);
             else
                 hipLaunchKernelGGL((pyramid_tail_fast_kernel<5, 6, 8, 10, 13, false>), dim3(1, 1, batch), dim3(1024),
-                                   TF_LDS_BYTES, st_tail, T, o_tail, tfk, thr, d_cand, cap, d_cnt, zs);
+                                   TF_LDS_BYTES, st_tail, T, o_tail, tfk, thr, d_cand, cap, d_cnt, zs, -1);
         } else if (o_tail < n_oct) {
             TailK tk;
             memset(&tk, 0, sizeof(tk));
@@ -1819,12 +1842,12 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // ---- the extraction's one synchronisation: the counters and (a guess of) the records of every image
         int kp_hint = std::min(2 * cap, S->kp_hint > 0 ? S->kp_hint : 8192);
         if (dev_sort) kp_hint = std::min(kp_hint, SORT_CAP);
-        const size_t cnt_bytes = al((size_t)batch * 16);
+        const size_t cnt_bytes = al((size_t)batch * 32);
         DBG_STEP("pinned block: reserve");
         rc = imatch_hs_reserve(ctx, cnt_bytes + (size_t)batch * kp_hint * sizeof(KpRec));
         if (rc) return rc;
         DBG_STEP("pinned block reserved");
-        int* h_cnt = (int*)ctx->hs;                              // [batch][4]
+        int* h_cnt = (int*)ctx->hs;                              // [batch][8]: candidates, refined, records, sorted records, timed-out octave + 1
         KpRec* h_kp = (KpRec*)((char*)ctx->hs + cnt_bytes);      // [batch][kp_hint]
         // ends the record copy on the second stream on every way out of this attempt
         struct CopyGuard {
@@ -1834,7 +1857,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             ~CopyGuard() { (void)wait(); }
         } rec_copy{nullptr, false};
         const bool copy_aside = dev_sort && (size_t)batch * kp_hint * sizeof(KpRec) >= ((size_t)1 << 20);
-        HIP_TRY(ctx, hipMemcpy2DAsync(h_cnt, 16, d_cnt, zs, 16, (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpy2DAsync(h_cnt, 32, d_cnt, zs, 32, (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
         if (copy_aside) {
             if (!S->copy) {
                 HIP_TRY(ctx, hipStreamCreateWithFlags(&S->copy, hipStreamNonBlocking));
@@ -1856,13 +1879,26 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         DBG_STEP("counts are here");
         const double t_b = now_ms();
-        int max_cand = 0, max_ref = 0, max_kp = 0;
+        int max_cand = 0, max_ref = 0, max_kp = 0, timed_out = 0;
         for (int b = 0; b < batch; ++b) {
-            if (h_cnt[4 * b] < 0)
-                return imatch_set_err(ctx, IMATCH_EHIP, "scale space, small octaves: a workgroup waited in vain for the octave before it");
-            max_cand = std::max(max_cand, h_cnt[4 * b]);
-            max_ref = std::max(max_ref, h_cnt[4 * b + 1]);
-            max_kp = std::max(max_kp, h_cnt[4 * b + 2]);
+            if (h_cnt[8 * b] < 0) timed_out = std::max(timed_out, std::max(h_cnt[8 * b + 4], 1));
+            max_cand = std::max(max_cand, h_cnt[8 * b]);
+            max_ref = std::max(max_ref, h_cnt[8 * b + 1]);
+            max_kp = std::max(max_kp, h_cnt[8 * b + 2]);
+        }
+        if (timed_out) {
+            // the workgroup of octave timed_out - 1 of the small-octave kernel waited about a second for the octave before
+            // it: some workgroup of that launch never became resident (something else held the CUs it needs). The
+            // one-workgroup walk depends on nobody: run the extraction again with it, and keep to it on this context.
+            HIP_TRY(ctx, rec_copy.wait());
+            if (!used_tail_split)
+                return imatch_set_err(ctx, IMATCH_EHIP, "scale space: candidate counter poisoned (octave %d) without the octave hand-off in use",
+                                      timed_out - 1);
+            fprintf(stderr, "[imatch] scale space, small octaves: octave %d waited in vain for octave %d's layer %d; running the "
+                            "extraction again with the one-workgroup walk (kept from now on for this context)\n",
+                    timed_out - 1, timed_out - 2, nl);
+            S->no_tail_split = true;
+            continue;
         }
         if (max_cand > cap) {  // rare: grow the lists and run the batch again
             cap = max_cand + max_cand / 8;
@@ -1876,7 +1912,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         S->ref_hint = max_ref + max_ref / 4 + 256;
         S->kp_hint = max_kp + max_kp / 4 + 1024;
         std::vector<int> n_kp((size_t)batch);
-        for (int b = 0; b < batch; ++b) n_kp[b] = h_cnt[4 * b + 2];
+        for (int b = 0; b < batch; ++b) n_kp[b] = h_cnt[8 * b + 2];
         bool refetch = false;
         if (dev_sort && max_kp > n_sort) {   // more records than the device sort was launched for: the host sorts the raw ones
             dev_sort = false;
@@ -1887,7 +1923,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if (dev_sort) {
             max_fetch = 0;
             for (int b = 0; b < batch; ++b) {
-                K_dev[b] = h_cnt[4 * b + 3];
+                K_dev[b] = h_cnt[8 * b + 3];
                 max_fetch = std::max(max_fetch, K_dev[b]);
             }
         }
@@ -2107,6 +2143,21 @@ int imatch_sift_debug_layer(imatch_ctx* ctx, int kind, int o, int i, float* out,
             for (size_t q = 0; q < n; ++q) out[q] = hi[q] - out[q];
         }
     }
+    return IMATCH_OK;
+}
+
+// rows [row0, row0 + nrows) of Gaussian layer i of octave o of the last extraction (a 32768^2 layer is 4.3 GB: the
+// full-size tests look at it in bands)
+int imatch_sift_debug_layer_rows(imatch_ctx* ctx, int o, int i, int row0, int nrows, float* out) {
+    if (!ctx || !ctx->sift || !ctx->sift->arena) return imatch_set_err(ctx, IMATCH_EINVAL, "no extraction yet");
+    const PyrTable& T = ctx->sift->T;
+    if (o < 0 || o >= T.n_oct || i < 0 || i >= T.nl + 3) return imatch_set_err(ctx, IMATCH_EINVAL, "no such layer");
+    if (!out || row0 < 0 || nrows < 0 || row0 + nrows > T.rows[o]) return imatch_set_err(ctx, IMATCH_EINVAL, "rows outside the layer");
+    if (nrows == 0) return IMATCH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out, T.gauss[o][i] + (size_t)row0 * T.cols[o], (size_t)nrows * T.cols[o] * 4,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return IMATCH_OK;
 }
 

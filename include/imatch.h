@@ -179,6 +179,9 @@ int imatch_features_image(const imatch_features* f, uint8_t* out, int h, int w);
  * out may be null to query the size only. */
 int imatch_sift_debug_layer(imatch_ctx* ctx, int kind, int o, int i, float* out, int* rows, int* cols);
 int imatch_sift_debug_octaves(imatch_ctx* ctx);
+/* Same hook for a band of a Gaussian layer: rows [row0, row0 + nrows) of layer i of octave o, nrows x cols floats (a
+ * 32768^2 layer of a 16384^2 map is 4.3 GB; the full-size tests read it in bands). */
+int imatch_sift_debug_layer_rows(imatch_ctx* ctx, int o, int i, int row0, int nrows, float* out);
 
 /* AKAZE extraction --------------------------------------- */
 typedef struct imatch_akaze_params {
@@ -230,6 +233,9 @@ int imatch_knn2_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
  * array: calls that overlap in time on one GPU (two contexts, two streams) race; serialise them. */
 int imatch_knn2_noalloc_dev(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t,
                             int32_t idx_offset, int32_t* out4_dev);
+/* Test hook (no reference counterpart): the number of train chunks the last imatch_knn2* launch of this context walked
+ * the map in (one partial top-2 list per chunk; the fixed scratch block of imatch_knn2_noalloc_dev may force fewer). */
+int imatch_knn2_debug_last_chunks(imatch_ctx* ctx);
 /* The same query for float descriptors of any length d <= 128 (the 64-float M-SURF descriptors of the AKAZE path,
  * MF:182-183 with MF:210-211): dist = sqrtf of the f32 sum of squared differences accumulated in index order, ties
  * to the lower train index. Host pointers; q is [nq][d], t is [nt][d]. */

@@ -93,6 +93,8 @@ def _declare_sift(L):
     L.oracle_gauss_kernel.restype = c_int
     L.oracle_gauss_blur.argtypes = [_f32p, c_int, c_int, c_double, _f32p]
     L.oracle_gauss_blur.restype = None
+    L.oracle_upsample2_linear.argtypes = [_u8p, c_int, c_int, _f32p]
+    L.oracle_upsample2_linear.restype = None
     L.oracle_sift_run.argtypes = [_u8p, c_int, c_int, c_int, c_double, c_double, c_double, c_int]
     L.oracle_sift_run.restype = ctypes.c_void_p
     L.oracle_sift_free.argtypes = [ctypes.c_void_p]
@@ -147,6 +149,14 @@ def gauss_blur(img, sigma):
     img = np.ascontiguousarray(img, dtype=np.float32)
     out = np.empty_like(img)
     lib().oracle_gauss_blur(_p(img, _f32p), img.shape[0], img.shape[1], float(sigma), _p(out, _f32p))
+    return out
+
+
+def upsample2(img):
+    """createInitialImage's resize: u8 [h,w] -> f32 [2h,2w], INTER_LINEAR (Spec S1)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty((2 * img.shape[0], 2 * img.shape[1]), np.float32)
+    lib().oracle_upsample2_linear(_p(img, _u8p), img.shape[0], img.shape[1], _p(out, _f32p))
     return out
 
 

@@ -75,6 +75,34 @@ def test_overlay_bit_exact(ctx, shape):
     assert np.array_equal(ctx.draw_overlay(img, []), img)
 
 
+def test_overlay_far_end_points_same_pixels_bounded_work(ctx):
+    """A wild homography puts the quadrilateral's corners millions of pixels away. The kernel walks only the DDA steps
+    whose brush can touch the image: the pixels are the oracle's (which walks every step), and the time no longer grows
+    with the line's length or explodes with its thickness."""
+    import time
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (240, 320, 3), dtype=np.uint8)
+    far = 1 << 20
+    prims = [("line", (-far, -far + 37), (far, far), (255, 0, 0), 5),            # through the image, both ends far away
+             ("line", (far, 100), (-far + 11, 131), (0, 255, 0), 3),              # nearly horizontal, right to left
+             ("line", (160, -far), (171, far - 5), (0, 0, 255), 9),               # nearly vertical
+             ("line", (-far, -far), (-far + 50, -far + 3), 77, 2),                # nowhere near the image
+             ("line", (-40, 300), (far, -far), (9, 9, 9), 1),                     # one end near, outside
+             ("line", (10, 10), (300, 200), (200, 200, 0), 255)]                  # the thickest brush
+    got = ctx.draw_overlay(img, prims)
+    assert np.array_equal(got, oracle.draw_overlay(img, prims))
+    # beyond the library's coordinate range the wrapper clips the SEGMENT (its direction stays): a steep diagonal through
+    # the image centre still passes through it
+    wild = [("line", (160 - (1 << 33), 120 - (1 << 34)), (160 + (1 << 33), 120 + (1 << 34)), (255, 255, 255), 3)]
+    t0 = time.perf_counter()
+    out = ctx.draw_overlay(img, wild + [("line", (-(1 << 27), -(1 << 27) + 5), (1 << 27, 1 << 27), (1, 2, 3), 255)])
+    assert time.perf_counter() - t0 < 2.0
+    drawn = (ctx.draw_overlay(img, wild) != img).any(axis=2)
+    ys, xs = np.nonzero(drawn)
+    assert len(ys) > 300 and abs(np.polyfit(xs - 160.0, ys - 120.0, 1)[0] - 2.0) < 0.05 and drawn[120, 160]
+    assert (out != img).any()
+
+
 def test_overlay_rejects_what_it_cannot_draw(ctx):
     import image_matching_amd as im
     img = np.zeros((8, 8), np.uint8)

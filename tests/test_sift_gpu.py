@@ -201,3 +201,34 @@ def test_device_sort_and_its_host_fallback_agree_with_the_oracle():
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
     f0.free()
     c.close() if hasattr(c, "close") else None
+
+
+def test_octave_hand_off_time_out_falls_back_to_the_one_workgroup_walk(small_map, capfd):
+    """A single frame's small octaves run as one workgroup per octave, each waiting for a flag of the octave before it.
+    IMATCH_DEBUG_TAIL_WITHHOLD=0 makes the first of them never publish its flag: the next workgroup gives up after about
+    a second, the library says so on stderr, runs the extraction again with the one-workgroup walk (which waits for
+    nobody) and keeps to that form on the context. The result is the normal one, record for record."""
+    import os
+    img = np.ascontiguousarray(small_map[:480, :640])
+    c = im.Context(0)
+    try:
+        want_kp, want_d = c.sift_extract(img).download()
+        os.environ["IMATCH_DEBUG_TAIL_WITHHOLD"] = "0"
+        try:
+            got_kp, got_d = c.sift_extract(img).download()
+        finally:
+            del os.environ["IMATCH_DEBUG_TAIL_WITHHOLD"]
+        err = capfd.readouterr().err
+        assert "waited in vain" in err and "one-workgroup walk" in err, err
+        assert len(want_kp) > 500
+        assert np.array_equal(got_kp, want_kp) and np.array_equal(got_d, want_d)
+        # the context keeps to the one-workgroup walk: the knob no longer has anything to withhold
+        os.environ["IMATCH_DEBUG_TAIL_WITHHOLD"] = "0"
+        try:
+            again_kp, again_d = c.sift_extract(img).download()
+        finally:
+            del os.environ["IMATCH_DEBUG_TAIL_WITHHOLD"]
+        assert "waited in vain" not in capfd.readouterr().err
+        assert np.array_equal(again_kp, want_kp) and np.array_equal(again_d, want_d)
+    finally:
+        c.close()

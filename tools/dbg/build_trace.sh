@@ -1,8 +1,6 @@
-# development: libimatch.so with the kNN kernel's time stamps compiled in (rebuild with `python -m image_matching_amd.build --force` afterwards)
+# development: a second library with the kNN kernel's time stamps compiled in, beside the product (which is left alone):
+# image_matching_amd/libimatch_trace.so; run the trace tools with IMATCH_LIB pointing at it
 set -e
 cd "$(dirname "$0")/../.."
-python -m image_matching_amd.build >/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-honor-nans -DKNN_TRACE ${KT_FLAGS} -c image_matching_amd/csrc/knn.hip -o /tmp/knn_trace.o
-objs=$(ls image_matching_amd/csrc/build/*.o | grep -v '/knn.o')
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o image_matching_amd/libimatch.so $objs /tmp/knn_trace.o
-echo trace build done
+IMATCH_LIB_OUT=$PWD/image_matching_amd/libimatch_trace.so IMATCH_BUILD_DEFINES="-DKNN_TRACE ${KT_FLAGS}" python -m image_matching_amd.build --force >/dev/null
+echo "trace build done: IMATCH_LIB=$PWD/image_matching_amd/libimatch_trace.so python tools/dbg/knn_trace.py ..."
