@@ -59,12 +59,19 @@ def log(*a):
 
 
 def cpu_baseline(frames, map_desc_sample, n_map, map_xy_sample, ratio, threads):
-    """The same chain through the CPU oracle on this box's host cores, frame after frame for about two seconds of wall
-    time (`threads` OpenMP threads: tens of core-seconds). The kNN leg runs against the whole map when it holds at most
-    300 000 descriptors, else against a slice and is scaled linearly (it is a dense scan)."""
+    """The same chain through the CPU oracle on this box's host cores, frame after frame: up to 16 frames, bounded at about
+    25 s of wall time (`threads` OpenMP threads). The matcher is oracle.knn2_fast -- f32 rows, SIMD squared distances,
+    cache-tiled, square roots of the winners only: the shape of cv2.BFMatcher's own computation (oracle/knn_fast.c) --
+    and is checked against the scalar checker oracle.knn2 on the first frame, outside the timing. The kNN leg runs against
+    the whole map when it holds at most 300 000 descriptors, else against a slice and is scaled linearly (a dense scan)."""
     import oracle
     oracle.lib()
-    oracle.sift(oracle.clahe(frames[0]))          # first touch: page in the library, spin up the OpenMP pool
+    first = oracle.sift(oracle.clahe(frames[0]))          # first touch: page in the library, spin up the OpenMP pool
+    map_f32 = map_desc_sample.astype(np.float32)          # what cv2 holds: CV_32F rows
+    chk_i, chk_d = oracle.knn2(first.desc.astype(np.uint8), map_desc_sample, threads=threads)
+    fast_i, fast_d = oracle.knn2_fast(first.desc, map_f32, threads=threads)
+    if not (np.array_equal(chk_i, fast_i) and np.array_equal(chk_d, fast_d)):
+        raise RuntimeError("cpu_baseline: oracle.knn2_fast disagrees with the checker oracle.knn2")
     t_ext = t_knn_s = t_h = 0.0
     pairs = 0
     done = 0
@@ -74,7 +81,7 @@ def cpu_baseline(frames, map_desc_sample, n_map, map_xy_sample, ratio, threads):
         t0 = time.perf_counter()
         res = oracle.sift(oracle.clahe(frame))
         t1 = time.perf_counter()
-        idx, dist = oracle.knn2(res.desc.astype(np.uint8), map_desc_sample, threads=threads)
+        idx, dist = oracle.knn2_fast(res.desc, map_f32, threads=threads)
         t2 = time.perf_counter()
         gq, gt, _ = oracle.ratio(idx, dist, ratio)
         H = None
@@ -85,17 +92,20 @@ def cpu_baseline(frames, map_desc_sample, n_map, map_xy_sample, ratio, threads):
         t_ext += t1 - t0; t_knn_s += t2 - t1; t_h += t3 - t2
         pairs += len(res.desc) * len(map_desc_sample)
         done += 1
-        if time.perf_counter() - t_start > 2.0:
+        if time.perf_counter() - t_start > 25.0:
             break
     scale = n_map / max(len(map_desc_sample), 1)
     total = t_ext + t_knn_s * scale + t_h
+    gdist = pairs / t_knn_s / 1e9
     return {
         "value": done / total, "unit": "frames/s", "cores": threads, "kind": "port",
         "sample": "%d frames 640x480, %.1f s of wall time on %d threads: extract %.3f s/frame (OpenMP) + kNN vs %d map "
-                  "descriptors %.3f s/frame%s + ratio and homography %.4f s/frame; restatement of OpenCV, not OpenCV"
+                  "descriptors %.3f s/frame%s (SIMD, cache-tiled, f32 rows as cv2 holds them: %.2f Gdist/s = %.3f per core; "
+                  "checked against the scalar checker on the first frame) + ratio and homography %.4f s/frame; restatement of "
+                  "OpenCV, not OpenCV"
                   % (done, t_ext + t_knn_s + t_h, threads, t_ext / done, len(map_desc_sample), t_knn_s / done,
-                     "" if scale == 1 else " (scaled x%.1f to %d)" % (scale, n_map), t_h / done),
-        "knn_gdist_per_s": pairs / t_knn_s / 1e9,
+                     "" if scale == 1 else " (scaled x%.1f to %d)" % (scale, n_map), gdist, gdist / threads, t_h / done),
+        "knn_gdist_per_s": gdist, "knn_gdist_per_s_per_core": gdist / threads,
     }, kept
 
 
@@ -330,6 +340,25 @@ def main():
     log("[rank %d] map: %d descriptors, extract %.2fs (first) %.2fs (warm), scale-space stage %.2f ms"
         % (rank, n_real, t_map_extract, t_map_extract2, pyr_ms_map))
 
+    def build_shard(lo_, hi_):
+        """Rows [lo_, hi_) of the c3 / c5 descriptor map as a resident set: rows [0, n_real) are the orthomap's own
+        descriptors, the rest SURVEY 8(d)'s synthetic ones (any row range is reproducible on its own)."""
+        shard_u8 = torch.empty((hi_ - lo_, 128), dtype=torch.uint8, device=dev)
+        if lo_ < n_real:
+            real_u8 = torch.empty((n_real, 128), dtype=torch.uint8, device=dev)
+            f_map.desc_u8_dev(real_u8.data_ptr())
+            ctx.synchronize()
+            shard_u8[:min(hi_, n_real) - lo_] = real_u8[lo_:min(hi_, n_real)]
+            del real_u8
+        if hi_ > n_real:
+            a = max(lo_, n_real)
+            shard_u8[a - lo_:] = synth.synth_descriptors_dev(a - n_real, hi_ - n_real, dev, seed=7)
+        torch.cuda.synchronize(dev)
+        f = ctx.features_from_device_u8(shard_u8.data_ptr(), hi_ - lo_)
+        ctx.synchronize()
+        del shard_u8
+        return f
+
     # ---- the descriptor map of the workload, resident in HBM
     if workload == "c1":
         n_map, lo, hi = n_real, 0, n_real
@@ -340,19 +369,7 @@ def main():
         n_map = max(n_map, n_real)
         lo, hi = sharded.partition(n_map, world)[rank]
         t0 = time.time()
-        shard_u8 = torch.empty((hi - lo, 128), dtype=torch.uint8, device=dev)
-        if lo < n_real:      # rows [0, n_real) are the orthomap's own descriptors ...
-            real_u8 = torch.empty((n_real, 128), dtype=torch.uint8, device=dev)
-            f_map.desc_u8_dev(real_u8.data_ptr())
-            ctx.synchronize()
-            shard_u8[:min(hi, n_real) - lo] = real_u8[lo:min(hi, n_real)]
-            del real_u8
-        if hi > n_real:      # ... the rest SURVEY 8(d)'s synthetic ones (any row range is reproducible on its own)
-            a = max(lo, n_real)
-            shard_u8[a - lo:] = synth.synth_descriptors_dev(a - n_real, hi - n_real, dev, seed=7)
-        torch.cuda.synchronize(dev)
-        f_local = ctx.features_from_device_u8(shard_u8.data_ptr(), hi - lo)
-        del shard_u8
+        f_local = build_shard(lo, hi)
         matcher = sharded.ShardedMatcher(ctx, f_local, lo, dev)
         log("[rank %d] descriptor map: %d rows (%d real + synthetic), shard rows %d..%d resident in %.1fs"
             % (rank, n_map, n_real, lo, hi, time.time() - t0))
@@ -627,6 +644,70 @@ def main():
                               "all_gather of u8 query rows (128 B per row) + all_to_all of per-shard top-2 (16 B per query and rank)"),
                  "collective_backend": dist.get_backend(), "world_size_seen": dist.get_world_size()}
 
+    # ---- the OTHER workload of the default series, measured in this run (after the timed region, not part of `value`).
+    # The driver's series runs `--gpus 1` as c1 and `--gpus N > 1` as c3, so value(N) / value(1) of the headline compares two
+    # workloads; with both points on every line each workload has its own N-series: c1 is data-parallel (every rank the
+    # whole 236 k-row map, no collective), c3 the sharded 5 M-row map (match_dp).
+    def side_point(wl2, steps2, warm2):
+        nonlocal workload, replicated_frames, B, bq_cap, batches_d, matchers, n_map, stats
+        saved = (workload, replicated_frames, B, bq_cap, batches_d, matchers, n_map, stats)
+        f_side = None
+        try:
+            workload, replicated_frames = wl2, False
+            B = args.batch if args.batch > 1 else (256 if wl2 == "c1" else 64)
+            bq_cap = ((B * 3200 + 1023) // 1024) * 1024
+            n_sets2 = max(2, (len(frames_h) + B - 1) // B)
+            batches_d = [torch.from_numpy(np.stack([frames_h[(j * B + k) % len(frames_h)] for k in range(B)])).to(dev)
+                         for j in range(n_sets2)]
+            if wl2 == "c1":
+                n_map = n_real
+                mt = sharded.ShardedMatcher(ctx, f_map, 0, dev, local_only=True)
+                rows_here = n_real
+            else:
+                n_map = max(args.map_rows if args.map_rows > 0 else 5_000_000, n_real)
+                lo2, hi2 = sharded.partition(n_map, world)[rank]
+                f_side = build_shard(lo2, hi2)
+                mt = sharded.ShardedMatcher(ctx, f_side, lo2, dev)
+                rows_here = hi2 - lo2
+            matchers = [mt]
+            stats = {"kp": [], "good": [], "found": 0, "knn_ms": [], "pyr_ms": [], "q_launch": []}
+            run_steps(warm2, False)
+            barrier()
+            t_s = time.perf_counter()
+            run_steps(steps2, True)
+            barrier()
+            w2 = time.perf_counter() - t_s
+            if world > 1:
+                tw2 = torch.tensor([w2], dtype=torch.float64, device=dev)
+                sharded.all_reduce(tw2, dist.ReduceOp.MAX)
+                w2 = float(tw2.item())
+            k_ms = float(np.mean(stats["knn_ms"]))
+            ql = float(np.mean(stats["q_launch"]))
+            return {"workload_id": wl2, "value": world * B * steps2 / w2, "unit": "frames/s", "n_gpus": world,
+                    "steps": steps2, "warmup": warm2, "ms_per_step": w2 / steps2 * 1e3, "frames_per_step_per_gpu": B,
+                    "map_descriptors": n_map, "scaling": "weak", "knn_launch_ms": k_ms,
+                    "knn_frac_of_int8_peak": 256.0 * ql * rows_here / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TF,
+                    "homographies_found": "%d/%d" % (stats["found"], steps2 * B),
+                    "note": "measured in this run after the timed region, same step code and barriers as the headline; "
+                            "not part of value"}
+        finally:
+            try:
+                drain_tail()      # (a failure may have left a tail in flight: it reads B and the matchers)
+            except Exception:
+                pass
+            workload, replicated_frames, B, bq_cap, batches_d, matchers, n_map, stats = saved
+            if f_side is not None:
+                ctx.synchronize()
+                f_side.free()
+
+    series = None
+    if n_streams == 1 and B > 1 and workload in ("c1", "c3") and os.environ.get("IMATCH_BENCH_SERIES", "1") != "0":
+        other = "c3" if workload == "c1" else "c1"
+        try:
+            series = side_point(other, 6 if other == "c3" else 8, 2)
+        except Exception as e:      # must not take the headline down with it (every rank fails alike: sizes are the same)
+            series = {"workload_id": other, "error": repr(e)[:300]}
+
     # single-frame latency, outside the timed region: the per-frame calls, one frame at a time
     single_ms = None
     if world == 1:
@@ -693,19 +774,12 @@ def main():
         }
         if multi:
             out["multi_gpu"] = multi
-            # the same workload on ONE GPU (the whole map on it), kept from `bench.py --workload c3 --gpus 1`: the N = 1
-            # default run is workload c1 (a 236 k-row map), so value(N) / value(1) of the default series compares two
-            # workloads; this is the single-GPU point of THIS one. Not measured in this run.
-            try:
-                with open(os.path.join(ROOT, "profiles", "r2e_bench_c3_n1.json")) as fh:
-                    one = json.load(fh)
-                if workload == "c3" and one["config"]["map_descriptors"] == n_map and \
-                        one["config"]["frames_per_step_per_gpu"] == B * n_streams:
-                    multi["same_workload_on_one_gpu"] = {
-                        "value": one["value"], "unit": "frames/s", "ms_per_step": one["ms_per_step"],
-                        "source": "profiles/r2e_bench_c3_n1.json (bench.py --workload c3 --gpus 1), not measured in this run"}
-            except (OSError, ValueError, KeyError):
-                pass
+        # both workloads of the default series at THIS N: value(N) / value(1) exists per workload without a kept file
+        head = {"workload_id": workload, "value": fps, "unit": "frames/s", "n_gpus": world, "ms_per_step": wall / args.steps * 1e3,
+                "frames_per_step_per_gpu": B * n_streams, "map_descriptors": n_map, "note": "the headline (value)"}
+        out["series"] = {workload: head}
+        if series is not None:
+            out["series"][series["workload_id"]] = series
         # HBM-side traffic of the dominant kernel: NOT measured in this run -- it comes from separate rocprofv3 --pmc passes
         # over this same command, kept under profiles/, and is attached only when that measurement was taken on the
         # same launch shape

@@ -78,7 +78,8 @@ struct imatch_sift_state {
     // stream runs only what the NEXT octave waits for (layers 1..nl of every octave, then the small-octave kernel) and
     // the second stream runs each octave's layers nl+1, nl+2 and scan behind an event per octave (ev_oct).
     hipStream_t side;
-    hipEvent_t ev_fork, ev_join;
+    hipStream_t side2;           // chain-first order on large inputs: octaves >= 1's last two layers and scans (side has octave 0's)
+    hipEvent_t ev_fork, ev_join, ev_join2;
     hipEvent_t ev_oct[MAX_OCT];
     bool have_ev_oct;
     // A batch's sorted records (7 MB for 64 frames) go to the host on a stream of their own, beside the descriptor kernel:
@@ -104,6 +105,11 @@ void imatch_sift_state_free(imatch_ctx* ctx) {
         if (ctx->sift->have_ev_oct)
             for (int o = 0; o < MAX_OCT; ++o) (void)hipEventDestroy(ctx->sift->ev_oct[o]);
         (void)hipStreamDestroy(ctx->sift->side);
+    }
+    if (ctx->sift->side2) {
+        (void)hipStreamSynchronize(ctx->sift->side2);
+        (void)hipEventDestroy(ctx->sift->ev_join2);
+        (void)hipStreamDestroy(ctx->sift->side2);
     }
     free(ctx->sift);
     ctx->sift = nullptr;
@@ -1654,6 +1660,20 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // small inputs: the chain-splitting form (see imatch_sift_state)
         bool split = all_templated && n_oct > 1 && !use_side && o_tail >= 1 && nl == 3;
         if (const char* e = getenv("IMATCH_SIFT_SPLIT")) split = split && atoi(e) != 0;        // experiments
+        // Large inputs (maps, batches), chain first: the same split of every octave -- layers 1..nl on the main stream, the
+        // last two layers and the scan behind an event per octave -- with the per-layer marching kernels. The old order
+        // (octave 0 whole on the main stream, ALL later octaves one after the other on the second) ended with the small
+        // octaves' forty latency-bound launches running alone for 0.85 ms of the 8192^2 map's 6.7 ms after everything big had
+        // finished; now that chain is through 0.9 ms after octave 0's layer nl and the streams end on chip-filling
+        // kernels. Octave 0's tail goes to `side`, the later octaves' tails to `side2`, so that they run beside each other
+        // (IMATCH_SIFT_ORDER: 0 = old order, 1 = both on `side`).
+        const bool big = use_side;
+        static const int order_env = getenv("IMATCH_SIFT_ORDER") ? atoi(getenv("IMATCH_SIFT_ORDER")) : 2;
+        const bool chain_first = big && order_env != 0 && o_tail >= 1;
+        if (chain_first) {
+            use_side = false;
+            split = true;
+        }
         if ((use_side || split) && !S->side) {
             // Default priority. (Rounds 1-2 created this stream at the highest priority so that the later octaves' small
             // launches would get CU slots beside octave 0's big kernels. With TWO processes on one GPU -- the rehearsal
@@ -1665,6 +1685,11 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             HIP_TRY(ctx, hipStreamCreateWithFlags(&S->side, hipStreamNonBlocking));
             HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming));
+        }
+        const bool three = chain_first && order_env >= 2;
+        if (three && !S->side2) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&S->side2, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_join2, hipEventDisableTiming));
         }
         if (split && !S->have_ev_oct) {
             for (int o = 0; o < MAX_OCT; ++o) HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_oct[o], hipEventDisableTiming));
@@ -1689,7 +1714,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         bool have_l0 = true;   // layer 0 of octave o was written by the previous octave's layer-nl blur
         // layers 1..3 of an octave in one launch where the radii are the default ones (blur3_tile_kernel)
         float k3[3][2 * RT_MAXR + 1];
-        bool fuse3 = split && nl == 3;
+        bool fuse3 = split && nl == 3 && !chain_first;
         for (int i = 1; i <= 3 && fuse3; ++i) {
             static const int want_r[4] = {0, 5, 6, 8};
             const int n = gauss_kernel(sig[i], k3[i - 1], 2 * RT_MAXR + 1);
@@ -1709,14 +1734,15 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                                    batch, zs, nullptr);
                 if (rc) return rc;
             }
+            hipStream_t sb = (three && o > 0) ? S->side2 : S->side;
             HIP_TRY(ctx, hipEventRecord(S->ev_oct[o], ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(S->side, S->ev_oct[o], 0));
+            HIP_TRY(ctx, hipStreamWaitEvent(sb, S->ev_oct[o], 0));
             for (int i = nl + 1; i < nl + 3; ++i) {
-                rc = gaussian_blur(ctx, S->side, T.gauss[o][i - 1], nullptr, 0, 0, T.gauss[o][i], nullptr, d_tmp, rows, cols, sig[i],
+                rc = gaussian_blur(ctx, sb, T.gauss[o][i - 1], nullptr, 0, 0, T.gauss[o][i], nullptr, d_tmp, rows, cols, sig[i],
                                    batch, zs, nullptr);
                 if (rc) return rc;
             }
-            scan_octave(o, S->side);
+            scan_octave(o, sb);
         }
         for (int o = 0; o < o_tail && !split; ++o) {
             const int rows = T.rows[o], cols = T.cols[o];
@@ -1773,7 +1799,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             // space and little else runs: on maps and batches (use_side) it would wait beside octave 0's chip-filling
             // kernels for CUs with 155 KB of free LDS, and gains nothing measurable there. Never again on a context
             // where the hand-off once timed out.
-            used_tail_split = tail_split_env && !use_side && !S->no_tail_split && n_tail > 1 && n_tail <= 16 &&
+            used_tail_split = tail_split_env && !big && !S->no_tail_split && n_tail > 1 && n_tail <= 16 &&
                               batch * n_tail <= 32;
             // test knob (read on every call): the flag of this octave is never published, which forces the time-out path
             const char* wh = getenv("IMATCH_DEBUG_TAIL_WITHHOLD");
@@ -1805,6 +1831,10 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if (use_side || split) {
             HIP_TRY(ctx, hipEventRecord(S->ev_join, S->side));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, S->ev_join, 0));
+        }
+        if (three) {
+            HIP_TRY(ctx, hipEventRecord(S->ev_join2, S->side2));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, S->ev_join2, 0));
         }
         DBG_STEP("small octaves queued");
         if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));

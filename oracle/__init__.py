@@ -44,6 +44,8 @@ def _declare(L):
     L.oracle_knn2.restype = None
     L.oracle_knn2_u8.argtypes = [_u8p, _i64, _u8p, _i64, ctypes.c_int, _i32p, _f32p, ctypes.c_int]
     L.oracle_knn2_u8.restype = None
+    L.oracle_knn2_fast.argtypes = [_f32p, _i64, _f32p, _i64, ctypes.c_int, _i32p, _f32p, ctypes.c_int]
+    L.oracle_knn2_fast.restype = None
     L.oracle_ratio.argtypes = [_i32p, _f32p, _i64, ctypes.c_double, _i32p, _i32p, _f32p]
     L.oracle_ratio.restype = _i64
 
@@ -67,6 +69,18 @@ def knn2(q, t, threads=0):
     idx = np.empty((nq, 2), np.int32)
     dist = np.empty((nq, 2), np.float32)
     fn(_p(q, pt), nq, _p(t, pt), nt, d, _p(idx, _i32p), _p(dist, _f32p), threads)
+    return idx, dist
+
+
+def knn2_fast(q, t, threads=0):
+    """The CPU BASELINE's matcher (knn_fast.c): f32 rows, SIMD squared distances, cache-tiled, square roots of the winners
+    only -- the shape of cv2.BFMatcher(NORM_L2).knnMatch's own computation. Same result as knn2 on integer-valued rows."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    t = np.ascontiguousarray(t, dtype=np.float32)
+    nq, d = q.shape if q.ndim == 2 else (0, 128)
+    idx = np.empty((nq, 2), np.int32)
+    dist = np.empty((nq, 2), np.float32)
+    lib().oracle_knn2_fast(_p(q, _f32p), nq, _p(t, _f32p), t.shape[0], d, _p(idx, _i32p), _p(dist, _f32p), threads)
     return idx, dist
 
 

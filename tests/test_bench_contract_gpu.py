@@ -14,7 +14,7 @@ def test_bench_line(capsys, monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--map-side", "2048", "--batch", "8",
-                                      "--frames", "16"])
+                                      "--frames", "16", "--map-rows", "150001"])
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     bench.main()
@@ -31,7 +31,14 @@ def test_bench_line(capsys, monkeypatch):
     r = out["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 5000.0 and out["dtype"] == "i8"
     assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    # both workloads of the default N-series are measured in the run: the headline (c1 at N = 1) and the sharded-map one
+    se = out["series"]
+    assert se["c1"]["value"] == out["value"] and se["c1"]["n_gpus"] == 1
+    assert "error" not in se["c3"], se["c3"]
+    assert se["c3"]["value"] > 0 and se["c3"]["map_descriptors"] == 150001 and se["c3"]["n_gpus"] == 1
+    assert abs(se["c3"]["value"] - 8 * se["c3"]["steps"] / (se["c3"]["ms_per_step"] * se["c3"]["steps"] * 1e-3)) < 1e-6 * se["c3"]["value"]
     c = out["cpu_baseline"]
+    assert c["knn_gdist_per_s_per_core"] > 0
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
     p = out["parity"]
     assert "error" not in p, p
@@ -61,6 +68,10 @@ def test_bench_launches_its_own_ranks_and_runs_the_sharded_map(tmp_path):
         assert m["world_size_seen"] == 2 and m["identical_to_whole_map"] is True
         assert len(m["per_rank_knn_frac"]) == 2 and all(0 < f < 1 for f in m["per_rank_knn_frac"])
         assert m["per_rank_shard_rows"] == [75001, 75000] and m["exchange_us_per_step"] > 0
+        if workload == "c3":     # the data-parallel c1 point of the same N, measured in the run
+            se = out["series"]
+            assert se["c3"]["value"] == out["value"] and "error" not in se["c1"], se
+            assert se["c1"]["n_gpus"] == 2 and se["c1"]["value"] > 0
         frames = 8 * 2 * (2 if workload == "c3" else 1)
         assert abs(out["value"] - frames / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
         found, total = out["config"]["homographies_found"].split("/")

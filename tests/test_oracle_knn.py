@@ -61,3 +61,23 @@ def test_golden_knn_fixture():
     assert np.array_equal(idx, g["idx"]) and np.array_equal(dist, g["dist"])
     gq, gt, gd = oracle.ratio(idx, dist, 0.7)
     assert np.array_equal(gq, g["good_q"]) and np.array_equal(gt, g["good_t"])
+
+
+def test_fast_baseline_matcher_equals_the_checker():
+    """bench.py's cpu_baseline times oracle.knn2_fast (SIMD, cache-tiled, squared distances, the shape of OpenCV's own
+    computation); the checker stays oracle.knn2. On integer-valued rows they must agree index for index and distance for
+    distance, ties, odd query counts and missing neighbours included."""
+    t = synth.synth_descriptors(3000, seed=31)
+    t[2000:2100] = t[10:110]                      # ties: the lower index first
+    q, _, _ = synth.synth_queries(t, 257, seed=32, dup_frac=0.1)
+    for nt in (3000, 513, 512, 2, 1, 0):
+        for threads in (1, 3):
+            i1, d1 = oracle.knn2(q, t[:nt], threads=threads)
+            i2, d2 = oracle.knn2_fast(q.astype(np.float32), t[:nt].astype(np.float32), threads=threads)
+            assert np.array_equal(i1, i2) and np.array_equal(d1, d2), (nt, threads)
+    rng = np.random.default_rng(3)
+    q64 = rng.integers(0, 256, (50, 64)).astype(np.float32)
+    t64 = rng.integers(0, 256, (700, 64)).astype(np.float32)
+    i1, d1 = oracle.knn2(q64, t64)
+    i2, d2 = oracle.knn2_fast(q64, t64)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
