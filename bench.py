@@ -450,6 +450,8 @@ def main():
     # 13.8 ms step). One tail in flight at most; every tail has finished before a timed region ends (drain_tail).
     pipeline = B > 1 and n_streams == 1 and os.environ.get("IMATCH_BENCH_PIPELINE", "1") != "0"
     tail_ctx = im.Context(local_rank) if pipeline else None
+    if tail_ctx is not None:
+        tail_ctx.set_profiling(True)
     tail_err = []
     import queue
     tail_q = queue.Queue()
@@ -566,6 +568,10 @@ def main():
         wall = float(tw.item())
 
     # ---- after the timed region -------------------------------------------------------------------------------------
+    # the library's own stage brackets of the LAST step (HIP events on the streams the stages ran on)
+    stages_ms = dict(ctx.stage_times())
+    if tail_ctx is not None:
+        stages_ms.update({k: v for k, v in tail_ctx.stage_times().items() if k == "homography_score"})
     knn_ms = float(np.mean(stats["knn_ms"]))
     q_launch = float(np.mean(stats["q_launch"]))
     achieved_tf = 256.0 * q_launch * n_local / (knn_ms * 1e-3) / 1e12     # 256 flop per (query, train) pair
@@ -772,6 +778,8 @@ def main():
                                          "kernels move (each blur reads and writes a layer once, the scan reads six layers, "
                                          "the base blur reads the u8 image; PMC-confirmed, profiles/)"},
         }
+        out["stages_ms"] = dict(stages_ms, note="event brackets of the last timed step's stages inside the library "
+                                                "(imatch_stage_times), per step of %d frames" % (B * n_streams))
         if multi:
             out["multi_gpu"] = multi
         # both workloads of the default series at THIS N: value(N) / value(1) exists per workload without a kept file

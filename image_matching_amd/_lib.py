@@ -59,6 +59,8 @@ SIGNATURES = {
     "imatch_set_profiling": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "imatch_knn2_kernel_ms": (ctypes.c_int, [c_vp, c_f32p]),
     "imatch_sift_pyramid_ms": (ctypes.c_int, [c_vp, c_f32p]),
+    "imatch_stage_times": (ctypes.c_int, [c_vp, c_f32p, ctypes.c_int]),
+    "imatch_stage_name": (ctypes.c_char_p, [ctypes.c_int]),
     "imatch_features_from_host_f32": (ctypes.c_int, [c_vp, c_f32p, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_features_from_host_u8": (ctypes.c_int, [c_vp, c_u8p, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "imatch_features_from_device_u8": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, ctypes.POINTER(c_vp)]),
@@ -311,6 +313,15 @@ class Context:
         with self.lock:
             self._check(self.lib.imatch_knn2_kernel_ms(self._h, ctypes.byref(ms)))
         return ms.value
+
+    def stage_times(self):
+        """{stage name: ms of its last bracket} for every stage that has run since set_profiling(True) (imatch_stage_times):
+        clahe, scale_space, keypoints, describe, knn, knn_merge, ratio, homography_score."""
+        n = 8
+        ms = np.zeros(n, np.float32)
+        with self.lock:
+            self._check(self.lib.imatch_stage_times(self._h, _ptr(ms, c_f32p), n))
+        return {self.lib.imatch_stage_name(i).decode(): float(ms[i]) for i in range(n) if ms[i] >= 0}
 
     def sift_pyramid_ms(self):
         ms = ctypes.c_float(0)

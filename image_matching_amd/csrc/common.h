@@ -24,10 +24,10 @@ struct imatch_ctx {
     // pinned staging of host images on their way to / from the device (see imatch_stage_upload)
     void* is;
     size_t is_bytes;
-    // optional event bracket around the dominant kernel (imatch_set_profiling)
+    // optional event brackets around the stages of the path (imatch_set_profiling, imatch_stage_times): [stage][begin, end]
     int prof;
-    hipEvent_t ev0, ev1;   // kNN MFMA kernel
-    hipEvent_t ev2, ev3;   // SIFT scale-space stage (upsample .. last extrema scan)
+    hipEvent_t st_ev[IMATCH_STAGE_COUNT][2];
+    unsigned st_seen;      // bit s: stage s has been bracketed at least once since profiling was switched on
     int knn_last_chunks;   // train chunks of the last kNN launch (imatch_knn2_debug_last_chunks)
     // SIFT pyramid arena of the last extraction (kept for reuse by the next frame of the same size)
     struct imatch_sift_state* sift;
@@ -78,6 +78,10 @@ void imatch_sift_state_free(imatch_ctx* ctx);
 void imatch_camera_state_free(imatch_ctx* ctx);
 void imatch_akaze_state_free(imatch_ctx* ctx);
 int imatch_set_err(imatch_ctx* ctx, int code, const char* fmt, ...);
+// Stage brackets (core.hip): with profiling on, an event on `st` and a roctx range (when libroctx64 is loadable) at both
+// ends of a stage; nothing otherwise. Return a hipError_t-free int: IMATCH_OK or IMATCH_EHIP with the message set.
+int imatch_stage_begin(imatch_ctx* ctx, int stage, hipStream_t st);
+int imatch_stage_end(imatch_ctx* ctx, int stage, hipStream_t st);
 int imatch_ws_reserve(imatch_ctx* ctx, size_t bytes);
 // Per-context device block pool: a frame's descriptor set, image copy and result lists come from here,
 // so the per-frame path calls neither hipMalloc nor hipFree (hipFree drains the device). Blocks are

@@ -1,5 +1,7 @@
 // Context, error handling and workspace management of libimatch.so.
 #include "common.h"
+#include <dlfcn.h>
+#include <mutex>
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -280,10 +282,9 @@ void imatch_destroy(imatch_ctx* ctx) {
     imatch_workers_destroy(ctx);
     if (ctx->hs) (void)hipHostFree(ctx->hs);
     if (ctx->is) (void)hipHostFree(ctx->is);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
-    if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
+    for (int s = 0; s < IMATCH_STAGE_COUNT; ++s)
+        for (int e = 0; e < 2; ++e)
+            if (ctx->st_ev[s][e]) (void)hipEventDestroy(ctx->st_ev[s][e]);
     if (ctx->hs_ev) (void)hipEventDestroy(ctx->hs_ev);
     (void)hipStreamDestroy(ctx->stream);
     free(ctx);
@@ -293,33 +294,90 @@ const char* imatch_last_error(const imatch_ctx* ctx) { return ctx ? ctx->err : "
 
 void* imatch_stream(imatch_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+// roctx ranges, when the tracer's marker library is there (it is part of ROCm but not a link dependency of this library)
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+static roctx_push_fn roctx_push = nullptr;
+static roctx_pop_fn roctx_pop = nullptr;
+static std::once_flag roctx_once;
+static void roctx_load() {
+    std::call_once(roctx_once, [] {
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+        roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+        if (!roctx_push || !roctx_pop) roctx_push = nullptr, roctx_pop = nullptr;
+    });
+}
+
+static const char* const stage_names[IMATCH_STAGE_COUNT] = {"imatch:clahe", "imatch:scale_space", "imatch:keypoints",
+                                                            "imatch:describe", "imatch:knn", "imatch:knn_merge",
+                                                            "imatch:ratio", "imatch:homography_score"};
+
+const char* imatch_stage_name(int stage) {
+    return stage >= 0 && stage < IMATCH_STAGE_COUNT ? stage_names[stage] + 7 : "";
+}
+
 int imatch_set_profiling(imatch_ctx* ctx, int on) {
     if (!ctx) return IMATCH_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (on && !ctx->ev0) {
-        HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
-        HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
-        HIP_TRY(ctx, hipEventCreate(&ctx->ev2));
-        HIP_TRY(ctx, hipEventCreate(&ctx->ev3));
+    if (on && !ctx->st_ev[0][0]) {
+        for (int s = 0; s < IMATCH_STAGE_COUNT; ++s)
+            for (int e = 0; e < 2; ++e) HIP_TRY(ctx, hipEventCreate(&ctx->st_ev[s][e]));
+        roctx_load();
     }
+    if (on && !ctx->prof) ctx->st_seen = 0;
     ctx->prof = on ? 1 : 0;
+    return IMATCH_OK;
+}
+
+extern "C++" int imatch_stage_begin(imatch_ctx* ctx, int stage, hipStream_t st) {
+    if (!ctx->prof) return IMATCH_OK;
+    if (roctx_push) (void)roctx_push(stage_names[stage]);
+    HIP_TRY(ctx, hipEventRecord(ctx->st_ev[stage][0], st));
+    return IMATCH_OK;
+}
+
+extern "C++" int imatch_stage_end(imatch_ctx* ctx, int stage, hipStream_t st) {
+    if (!ctx->prof) return IMATCH_OK;
+    if (roctx_pop) (void)roctx_pop();
+    HIP_TRY(ctx, hipEventRecord(ctx->st_ev[stage][1], st));
+    ctx->st_seen |= 1u << stage;
+    return IMATCH_OK;
+}
+
+static int stage_ms(imatch_ctx* ctx, int stage, float* ms) {
+    if (!ctx->st_ev[0][0]) return imatch_set_err(ctx, IMATCH_EINVAL, "profiling was never enabled");
+    if (!(ctx->st_seen & (1u << stage))) { *ms = -1.f; return IMATCH_OK; }
+    HIP_TRY(ctx, hipEventSynchronize(ctx->st_ev[stage][1]));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->st_ev[stage][0], ctx->st_ev[stage][1]));
+    return IMATCH_OK;
+}
+
+int imatch_stage_times(imatch_ctx* ctx, float* ms, int n) {
+    if (!ctx || !ms || n < 0 || n > IMATCH_STAGE_COUNT) return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int s = 0; s < n; ++s) {
+        const int rc = stage_ms(ctx, s, ms + s);
+        if (rc) return rc;
+    }
     return IMATCH_OK;
 }
 
 int imatch_knn2_kernel_ms(imatch_ctx* ctx, float* ms) {
     if (!ctx || !ms) return IMATCH_EINVAL;
-    if (!ctx->ev0) return imatch_set_err(ctx, IMATCH_EINVAL, "profiling was never enabled");
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
-    return IMATCH_OK;
+    const int rc = stage_ms(ctx, IMATCH_STAGE_KNN, ms);
+    if (rc == IMATCH_OK && *ms < 0) return imatch_set_err(ctx, IMATCH_EINVAL, "no kNN launch since profiling was switched on");
+    return rc;
 }
 
 int imatch_sift_pyramid_ms(imatch_ctx* ctx, float* ms) {
     if (!ctx || !ms) return IMATCH_EINVAL;
-    if (!ctx->ev2) return imatch_set_err(ctx, IMATCH_EINVAL, "profiling was never enabled");
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev3));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev2, ctx->ev3));
-    return IMATCH_OK;
+    const int rc = stage_ms(ctx, IMATCH_STAGE_SCALE_SPACE, ms);
+    if (rc == IMATCH_OK && *ms < 0) return imatch_set_err(ctx, IMATCH_EINVAL, "no extraction since profiling was switched on");
+    return rc;
 }
 
 int imatch_synchronize(imatch_ctx* ctx) {

@@ -248,9 +248,11 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
     HIP_TRY(ctx, hipMemsetAsync(d_best, 0, kbytes, ctx->stream));
     // one problem: single-wave workgroups, or its 4096 hypotheses sit on 16 of the 256 CUs
     const int wg = nseg >= 8 ? 256 : 64;
+    (void)imatch_stage_begin(ctx, IMATCH_STAGE_HOMOGRAPHY, ctx->stream);
     hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / wg, nseg), dim3(wg), 0, ctx->stream,
                        (const double*)dev, (const float*)(dev + dbytes), hs, d_best);
     HIP_TRY(ctx, hipGetLastError());
+    (void)imatch_stage_end(ctx, IMATCH_STAGE_HOMOGRAPHY, ctx->stream);
     unsigned long long* h_key = (unsigned long long*)((char*)ctx->hs + up_bytes);  // pinned: no staging copy
     HIP_TRY(ctx, hipMemcpyAsync(h_key, d_best, kbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

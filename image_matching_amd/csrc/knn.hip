@@ -824,7 +824,7 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     int2* pi = (int2*)((char*)ws + pbytes);
     int* gthr = (int*)((char*)ws + 2 * pbytes);
     HIP_TRY(ctx, hipMemsetAsync(gthr, 0x7f, gbytes, ctx->stream));  // KNN_INF in every word
-    if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    { const int rcs = imatch_stage_begin(ctx, IMATCH_STAGE_KNN, ctx->stream); if (rcs) return rcs; }
     {
         const unsigned grid = (unsigned)(nQt * nChunks);
         const int rot = rot_on && grid > 2u * slots;
@@ -843,10 +843,12 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
 #undef KARGS
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    { const int rcs = imatch_stage_end(ctx, IMATCH_STAGE_KNN, ctx->stream); if (rcs) return rcs; }
+    { const int rcs = imatch_stage_begin(ctx, IMATCH_STAGE_KNN_MERGE, ctx->stream); if (rcs) return rcs; }
     hipLaunchKernelGGL(knn2_finish_kernel, dim3((unsigned)((q->n + 15) / 16)), dim3(256), 0, ctx->stream, pb, pi,
                        (int)nLists, Qpad, q->norm, q->n, t->n, idx_offset, (int4*)out4_dev);
     HIP_TRY(ctx, hipGetLastError());
+    { const int rcs = imatch_stage_end(ctx, IMATCH_STAGE_KNN_MERGE, ctx->stream); if (rcs) return rcs; }
     return IMATCH_OK;
 }
 
@@ -998,9 +1000,11 @@ static int ratio_run(imatch_ctx* ctx, const int32_t* out4_dev, const imatch_segt
     if (!dev) return imatch_set_err(ctx, IMATCH_ENOMEM, "match lists for %lld queries", (long long)nq);
     int rc = imatch_hs_reserve(ctx, 3 * arr + cnt);
     if (rc) { imatch_pool_free(ctx, dev); return rc; }
+    (void)imatch_stage_begin(ctx, IMATCH_STAGE_RATIO, ctx->stream);
     hipLaunchKernelGGL(ratio_kernel, dim3(seg.n), dim3(1024), 0, ctx->stream, (const int4*)out4_dev, seg, ratio, (int*)dev,
                        (int*)(dev + arr), (float*)(dev + 2 * arr), (unsigned long long*)(dev + 3 * arr));
     hipError_t e = hipGetLastError();
+    (void)imatch_stage_end(ctx, IMATCH_STAGE_RATIO, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->hs, dev, 3 * arr + cnt, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     imatch_pool_free(ctx, dev);

@@ -390,6 +390,99 @@ detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ 
     stage_flush_block(stage, n_staged, wcnt, cand, cap, count);
 }
 
+// The same scan with V adjacent columns per lane (V = 2 or 4: one 8- or 16-byte load per lane, row and layer). The scan is
+// bound by instruction issue, not by bytes (about 150 instructions per wave and row for 62 pixels; profiles/): with V
+// columns per lane the row's fixed costs -- address arithmetic, the exec-mask work around the rare appends, the loop -- and
+// the lane exchanges (two per DoG layer and row, for the lane's outer columns only) are shared by V times the pixels. A wave
+// loads 64 V columns starting at xb = 4 + (64 V - V) k (a multiple of V, so every load is aligned) and owns the outputs
+// xb + 1 .. xb + 64 V - V; consecutive strips overlap by V columns. Needs cols % V == 0; same predicate, same records.
+template <int V>
+__global__ void __launch_bounds__(256)
+detect_streamv_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count,
+                      size_t zs) {
+    typedef float vf __attribute__((ext_vector_type(V)));
+    constexpr int OUTW = 64 * V - V;
+    const size_t zo = (size_t)blockIdx.z * zs;
+    cand = ZP(cand); count = ZP(count);
+    const int cols = T.cols[o], rows = T.rows[o];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int xb = (SIFT_IMG_BORDER - 1) + blockIdx.x * OUTW;
+    const int c0 = xb + V * lane;
+    const int ry0 = SIFT_IMG_BORDER + (blockIdx.y * 4 + wv) * rpw;
+    __shared__ uint2 stage_all[4][DET_STAGE];
+    __shared__ int wcnt[5];
+    uint2* stage = stage_all[wv];
+    int n_staged = 0;
+    const bool wave_active = ry0 < rows - SIFT_IMG_BORDER;  // wave-uniform
+    const int cl = min(c0, cols - V);                       // lanes past the row's end re-read its last group (never an output)
+    const float* p[6];
+#pragma unroll
+    for (int l = 0; l < 6; ++l) p[l] = TG(o, l) + cl;
+    bool col_ok[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) col_ok[e] = c0 + e > xb && c0 + e <= xb + OUTW && c0 + e < cols - SIFT_IMG_BORDER;
+    float hm[5][3][V], hn[5][3][V], cv[3][3][V];
+    auto load_row = [&](int row, int slot) {
+        const size_t off = (size_t)min(row, rows - 1) * cols;
+        vf g[6];
+#pragma unroll
+        for (int l = 0; l < 6; ++l) g[l] = *(const vf*)(p[l] + off);
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            const vf v = g[l + 1] - g[l];
+            const float left = __shfl_up(v[V - 1], 1), right = __shfl_down(v[0], 1);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float a = e > 0 ? v[e - 1] : left, d = e < V - 1 ? v[e + 1] : right;
+                hm[l][slot][e] = fmaxf(fmaxf(a, v[e]), d);
+                hn[l][slot][e] = fminf(fminf(a, v[e]), d);
+                if (l >= 1 && l <= 3) cv[l - 1][slot][e] = v[e];
+            }
+        }
+    };
+    if (wave_active) {
+        load_row(ry0 - 1, 0);
+        load_row(ry0, 1);
+    }
+    for (int k = 0; wave_active && k < rpw; k += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int r = ry0 + k + u;            // output row: rows r-1, r, r+1 sit in the three slots
+            load_row(r + 1, (u + 2) % 3);
+            const bool row_ok = k + u < rpw && r < rows - SIFT_IMG_BORDER;
+            bool hit[3][V];
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float M[5], m[5];
+#pragma unroll
+                for (int l = 0; l < 5; ++l) {
+                    M[l] = fmaxf(fmaxf(hm[l][0][e], hm[l][1][e]), hm[l][2][e]);
+                    m[l] = fminf(fminf(hn[l][0][e], hn[l][1][e]), hn[l][2][e]);
+                }
+#pragma unroll
+                for (int i = 1; i <= 3; ++i) {
+                    const float val = cv[i - 1][(u + 1) % 3][e];
+                    const bool is_max = val > thr && val >= fmaxf(fmaxf(M[i - 1], M[i]), M[i + 1]);
+                    const bool is_min = val < -thr && val <= fminf(fminf(m[i - 1], m[i]), m[i + 1]);
+                    hit[i - 1][e] = row_ok && col_ok[e] && (is_max || is_min);
+                    any = any || hit[i - 1][e];
+                }
+            }
+            if (__ballot(any) != 0) {   // wave-uniform; a few per cent of the rows
+#pragma unroll
+                for (int i = 1; i <= 3; ++i)
+#pragma unroll
+                    for (int e = 0; e < V; ++e)
+                        stage_append<uint2, DET_STAGE>(stage, n_staged, hit[i - 1][e],
+                                                       make_uint2((unsigned)((o << 8) | i), (unsigned)((r << 16) | (c0 + e))), cand,
+                                                       cap, count);
+            }
+        }
+    }
+    stage_flush_block(stage, n_staged, wcnt, cand, cap, count);
+}
+
 // ---- the small octaves: one workgroup, LDS-resident ----------------------------------------------
 // From the first octave of at most TAIL_MAXPX pixels on (60x80 for a 640x480 frame) a launch per layer
 // is all latency: 7 launches per octave for a few thousand pixels. One 1024-thread workgroup instead
@@ -1627,16 +1720,18 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             if (rcu) return rcu;
         }
         if (P->clahe) {
+            (void)imatch_stage_begin(ctx, IMATCH_STAGE_CLAHE, ctx->stream);
             int rc = imatch_clahe_dev(ctx, d_src, h, w, src_stride, P->clahe_clip, P->clahe_tiles_x, P->clahe_tiles_y, d_clahe,
                                       A + o_cscr, batch, src_zs, zs);
             if (rc) return rc;
+            (void)imatch_stage_end(ctx, IMATCH_STAGE_CLAHE, ctx->stream);
             d_src = d_clahe;
             src_stride = w;
             src_zs = zs;
         }
         if (batch == 1) HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
         else HIP_TRY(ctx, hipMemset2DAsync(d_cnt, zs, 0, 256, (size_t)batch, ctx->stream));
-        if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+        { const int rcs = imatch_stage_begin(ctx, IMATCH_STAGE_SCALE_SPACE, ctx->stream); if (rcs) return rcs; }
         bool fused = false;
         int rc = gaussian_blur(ctx, ctx->stream, nullptr, d_src, src_stride, src_zs, T.gauss[0][0], nullptr, d_tmp, brows, bcols,
                                sig_diff, batch, zs, &fused);
@@ -1704,8 +1799,19 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             if (nl == 3) {
                 const size_t px = (size_t)iw * ih * batch;
                 const int rpw = px >= ((size_t)1 << 26) ? 64 : px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
-                hipLaunchKernelGGL(detect_stream_kernel, dim3((iw + DS_COLS - 1) / DS_COLS, (ih + 4 * rpw - 1) / (4 * rpw), batch),
-                                   dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs);
+                // columns per lane (profiles/r3_scanv_sweep.txt): 4 on the 32768^2 layers of a 16384^2 map (scale space 25.1 ->
+                // 22.6 ms; 24.1 with 2), 2 elsewhere (8192^2 map 6.43 -> 6.11 ms; 6.26 with 4: fewer waves per SIMD), 1 where
+                // the rows are odd or narrower than a strip (IMATCH_SIFT_SCANV = 1 / 2 / 4 forces a form where it is possible)
+                static const int scanv_env = getenv("IMATCH_SIFT_SCANV") ? atoi(getenv("IMATCH_SIFT_SCANV")) : 0;
+                int V = (cols % 4 == 0 && (size_t)iw * ih >= ((size_t)1 << 29)) ? 4 : (cols % 2 == 0 && iw >= 126) ? 2 : 1;
+                if (scanv_env == 1 || (scanv_env == 2 && cols % 2 == 0) || (scanv_env == 4 && cols % 4 == 0)) V = scanv_env;
+                const dim3 grid((iw + (V == 1 ? DS_COLS : 63 * V) - 1) / (V == 1 ? DS_COLS : 63 * V), (ih + 4 * rpw - 1) / (4 * rpw), batch);
+                if (V == 4)
+                    hipLaunchKernelGGL(detect_streamv_kernel<4>, grid, dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs);
+                else if (V == 2)
+                    hipLaunchKernelGGL(detect_streamv_kernel<2>, grid, dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs);
+                else
+                    hipLaunchKernelGGL(detect_stream_kernel, grid, dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs);
             } else {
                 hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H, batch), dim3(256),
                                    0, st, T, o, thr, d_cand, cap, d_cnt, zs);
@@ -1837,7 +1943,8 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, S->ev_join2, 0));
         }
         DBG_STEP("small octaves queued");
-        if (ctx->prof) HIP_TRY(ctx, hipEventRecord(ctx->ev3, ctx->stream));
+        { const int rcs = imatch_stage_end(ctx, IMATCH_STAGE_SCALE_SPACE, ctx->stream); if (rcs) return rcs; }
+        (void)imatch_stage_begin(ctx, IMATCH_STAGE_KEYPOINTS, ctx->stream);
         // ---- refine + orientation are queued behind the scan without waiting for its count
         // (grid from the previous extraction's candidate count -- the kernel strides: sized by the list's CAPACITY, a batch
         // launched forty thousand workgroups of which a few hundred found a candidate)
@@ -1869,6 +1976,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                                zs);
             HIP_TRY(ctx, hipGetLastError());
         }
+        (void)imatch_stage_end(ctx, IMATCH_STAGE_KEYPOINTS, ctx->stream);
         // ---- the extraction's one synchronisation: the counters and (a guess of) the records of every image
         int kp_hint = std::min(2 * cap, S->kp_hint > 0 ? S->kp_hint : 8192);
         if (dev_sort) kp_hint = std::min(kp_hint, SORT_CAP);
@@ -2062,6 +2170,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             // IMATCH_DESC_WPK = 1 / 2 keeps the other forms for A/B runs.
             static const int wpk_env = getenv("IMATCH_DESC_WPK") ? atoi(getenv("IMATCH_DESC_WPK")) : 0;
             const int wpk = wpk_env ? wpk_env : 4;
+            (void)imatch_stage_begin(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
             if (wpk == 4)
                 hipLaunchKernelGGL(describe_kernel<4>, dim3(max_k, 1, batch), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted,
                                    seg, first_octave, f->desc, f->norm, f->tneg, zs);
@@ -2072,6 +2181,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                 hipLaunchKernelGGL(describe_kernel<1>, dim3((max_k + 3) / 4, 1, batch), dim3(256), 0, ctx->stream, T,
                                    (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs);
             HIP_TRY(ctx, hipGetLastError());
+            (void)imatch_stage_end(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
         }
         // the set's pad rows and flag (u8 rows are integral by type)
         rc = imatch_features_pad_dev(ctx, f);   // the rows themselves came from describe_kernel

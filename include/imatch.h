@@ -50,6 +50,23 @@ int imatch_synchronize(imatch_ctx* ctx);
  * imatch_knn2_kernel_ms waits for the last launch and returns its duration. */
 int imatch_set_profiling(imatch_ctx* ctx, int on);
 int imatch_knn2_kernel_ms(imatch_ctx* ctx, float* ms);
+/* Per-stage timers and trace ranges (tracing; no reference counterpart -- the reference logs one wall
+ * time per frame, position_finder.py:164,219). With profiling on, every stage of the path is bracketed by HIP events on
+ * the stream it runs on and by a roctx range of the same name around its enqueue (visible to rocprofv3 --marker-trace;
+ * skipped when libroctx64.so cannot be loaded). imatch_stage_times waits for the brackets recorded so far and writes
+ * the duration in ms of the LAST bracket of each stage into ms[0 .. n) (n <= IMATCH_STAGE_COUNT), -1 where a stage has not
+ * run since profiling was switched on. */
+#define IMATCH_STAGE_CLAHE        0   /* CLAHE inside imatch_sift_extract* (MF:200-203) */
+#define IMATCH_STAGE_SCALE_SPACE  1   /* base blur .. last extremum scan (MF:205-209,220) */
+#define IMATCH_STAGE_KEYPOINTS    2   /* refinement, orientation, sort + de-duplication */
+#define IMATCH_STAGE_DESCRIBE     3   /* descriptors into the matcher's row format */
+#define IMATCH_STAGE_KNN          4   /* the MFMA kNN kernel (MF:182-183) */
+#define IMATCH_STAGE_KNN_MERGE    5   /* merge of the per-chunk lists */
+#define IMATCH_STAGE_RATIO        6   /* ratio test + compaction (MF:191-194) */
+#define IMATCH_STAGE_HOMOGRAPHY   7   /* hypothesis scoring launch of imatch_homography* (MF:233) */
+#define IMATCH_STAGE_COUNT        8
+int imatch_stage_times(imatch_ctx* ctx, float* ms, int n);
+const char* imatch_stage_name(int stage);
 /* Same bracket around the scale-space stage of the last imatch_sift_extract (upsample, the Gaussian
  * / DoG kernels, decimation and the extrema scans): the stage SURVEY 8(d)'s 475.7 B/pixel covers. */
 int imatch_sift_pyramid_ms(imatch_ctx* ctx, float* ms);

@@ -232,3 +232,31 @@ def test_octave_hand_off_time_out_falls_back_to_the_one_workgroup_walk(small_map
         assert np.array_equal(again_kp, want_kp) and np.array_equal(again_d, want_d)
     finally:
         c.close()
+
+
+def test_stage_timers_cover_the_chain(small_map):
+    """SURVEY section 5, tracing: with profiling on every stage of the path is bracketed by events (and a roctx range);
+    imatch_stage_times gives the last bracket of each. One frame through extract -> kNN -> ratio -> homography."""
+    import torch
+    c = im.Context(0)
+    try:
+        c.set_profiling(True)
+        assert c.stage_times() == {}
+        fm = c.sift_extract(small_map)
+        ff = c.sift_extract(np.ascontiguousarray(small_map[100:580, 60:700]))
+        out4 = torch.empty((len(ff), 4), dtype=torch.int32, device="cuda:0")
+        c.knn2_dev(ff, fm, out4.data_ptr())
+        gq, gt, gd = c.ratio_dev(out4.data_ptr(), len(ff), 0.7)
+        kf, km = ff.download(descriptors=False)[0], fm.download(descriptors=False)[0]
+        assert len(gq) > 10
+        H, _ = c.homography(kf[gq, :2], km[gt, :2], 0.1, seed=1)
+        assert H is not None
+        st = c.stage_times()
+        assert set(st) == {"clahe", "scale_space", "keypoints", "describe", "knn", "knn_merge", "ratio", "homography_score"}
+        assert all(0 < v < 50 for v in st.values()), st
+        assert abs(st["scale_space"] - c.sift_pyramid_ms()) < 1e-6 and abs(st["knn"] - c.knn2_kernel_ms()) < 1e-6
+        c.set_profiling(False)
+        c.sift_extract(small_map).free()     # no brackets are recorded with profiling off: the old values stay
+        assert c.stage_times()["scale_space"] == st["scale_space"]
+    finally:
+        c.close()
