@@ -791,7 +791,7 @@ def main():
         # HBM-side traffic of the dominant kernel: NOT measured in this run -- it comes from separate rocprofv3 --pmc passes
         # over this same command, kept under profiles/, and is attached only when that measurement was taken on the
         # same launch shape
-        for pmc_file in ("r2_pmc_knn.json", "r1_pmc_knn.json"):
+        for pmc_file in ("r3_pmc_knn.json", "r2_pmc_knn.json", "r1_pmc_knn.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
                     pmc = json.load(fh)
@@ -803,6 +803,14 @@ def main():
                     break
             except (OSError, ValueError, KeyError):
                 pass
+        try:      # the same for the scale-space stage of the map extraction
+            with open(os.path.join(ROOT, "profiles", "r3_pmc_pyramid.json")) as fh:
+                pp = json.load(fh)
+            if args.map_side == 8192:
+                out["roofline_pyramid"]["traffic"] = pp["traffic_bytes_per_extraction"]
+                out["roofline_pyramid"]["traffic_note"] = "from profiles/r3_pmc_pyramid.json, not measured in this run: " + pp["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         if single_ms is not None:
             out["single_frame"] = {"ms_per_frame": single_ms, "frames_per_s": 1e3 / single_ms,
                                    "note": "one frame at a time through the single-frame entry points, measured after "

@@ -324,15 +324,31 @@ detect_kernel_generic(PyrTable T, int o, float thr, uint2* __restrict__ cand, in
 // separably and shared by the three layers that need them: val is a maximum iff
 // val >= max(M[i-1], M[i], M[i+1]), with M the 3x3 max that includes val itself.
 #define DS_COLS 62
+// The scans' grid is one-dimensional and XCD-aware like the blur's: consecutive workgroup ids go round-robin to the 8 XCDs,
+// so id -> (id % 8) * per + id / 8 gives every XCD a contiguous run of (row group, strip) pairs. A wave's row segment starts
+// at column 4 + 62 k (or 252 k, 126 k): not on a 128-byte line, so neighbouring strips share a line at each end; on one XCD
+// the second strip finds it in that XCD's L2, where strips dealt round-robin fetched it once per XCD (FETCH_SIZE of the
+// 4-byte-per-lane scan was 1.55 x the layers' bytes, calibrated with tools/fetch_calib.hip; profiles/r3_pmc.md).
+__device__ __forceinline__ bool scan_block(int nsx, int nsy, int& sx, int& sy) {
+    const int total = nsx * nsy, per = (total + 7) >> 3;
+    const int id = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (id >= total || (int)(blockIdx.x >> 3) >= per) return false;
+    sy = id / nsx;
+    sx = id - sy * nsx;
+    return true;
+}
+
 __global__ void __launch_bounds__(256)
 detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count,
-                     size_t zs) {
+                     size_t zs, int nsx, int nsy) {
+    int sx, sy;
+    if (!scan_block(nsx, nsy, sx, sy)) return;
     const size_t zo = (size_t)blockIdx.z * zs;
     cand = ZP(cand); count = ZP(count);
     const int cols = T.cols[o], rows = T.rows[o];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = SIFT_IMG_BORDER + blockIdx.x * DS_COLS + lane - 1;
-    const int ry0 = SIFT_IMG_BORDER + (blockIdx.y * 4 + wv) * rpw;
+    const int x = SIFT_IMG_BORDER + sx * DS_COLS + lane - 1;
+    const int ry0 = SIFT_IMG_BORDER + (sy * 4 + wv) * rpw;
     __shared__ uint2 stage_all[4][DET_STAGE];
     __shared__ int wcnt[5];
     uint2* stage = stage_all[wv];
@@ -399,16 +415,18 @@ detect_stream_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ 
 template <int V>
 __global__ void __launch_bounds__(256)
 detect_streamv_kernel(PyrTable T, int o, int rpw, float thr, uint2* __restrict__ cand, int cap, int* __restrict__ count,
-                      size_t zs) {
+                      size_t zs, int nsx, int nsy) {
+    int sx, sy;
+    if (!scan_block(nsx, nsy, sx, sy)) return;
     typedef float vf __attribute__((ext_vector_type(V)));
     constexpr int OUTW = 64 * V - V;
     const size_t zo = (size_t)blockIdx.z * zs;
     cand = ZP(cand); count = ZP(count);
     const int cols = T.cols[o], rows = T.rows[o];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int xb = (SIFT_IMG_BORDER - 1) + blockIdx.x * OUTW;
+    const int xb = (SIFT_IMG_BORDER - 1) + sx * OUTW;
     const int c0 = xb + V * lane;
-    const int ry0 = SIFT_IMG_BORDER + (blockIdx.y * 4 + wv) * rpw;
+    const int ry0 = SIFT_IMG_BORDER + (sy * 4 + wv) * rpw;
     __shared__ uint2 stage_all[4][DET_STAGE];
     __shared__ int wcnt[5];
     uint2* stage = stage_all[wv];
@@ -1805,13 +1823,15 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                 static const int scanv_env = getenv("IMATCH_SIFT_SCANV") ? atoi(getenv("IMATCH_SIFT_SCANV")) : 0;
                 int V = (cols % 4 == 0 && (size_t)iw * ih >= ((size_t)1 << 29)) ? 4 : (cols % 2 == 0 && iw >= 126) ? 2 : 1;
                 if (scanv_env == 1 || (scanv_env == 2 && cols % 2 == 0) || (scanv_env == 4 && cols % 4 == 0)) V = scanv_env;
-                const dim3 grid((iw + (V == 1 ? DS_COLS : 63 * V) - 1) / (V == 1 ? DS_COLS : 63 * V), (ih + 4 * rpw - 1) / (4 * rpw), batch);
+                const int ow = V == 1 ? DS_COLS : 63 * V;
+                const int nsx = (iw + ow - 1) / ow, nsy = (ih + 4 * rpw - 1) / (4 * rpw);
+                const dim3 grid((unsigned)((nsx * nsy + 7) & ~7), 1, batch);
                 if (V == 4)
-                    hipLaunchKernelGGL(detect_streamv_kernel<4>, grid, dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs);
+                    hipLaunchKernelGGL(detect_streamv_kernel<4>, grid, dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs, nsx, nsy);
                 else if (V == 2)
-                    hipLaunchKernelGGL(detect_streamv_kernel<2>, grid, dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs);
+                    hipLaunchKernelGGL(detect_streamv_kernel<2>, grid, dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs, nsx, nsy);
                 else
-                    hipLaunchKernelGGL(detect_stream_kernel, grid, dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs);
+                    hipLaunchKernelGGL(detect_stream_kernel, grid, dim3(256), 0, st, T, o, rpw, thr, d_cand, cap, d_cnt, zs, nsx, nsy);
             } else {
                 hipLaunchKernelGGL(detect_kernel_generic, dim3((iw + DT_W - 1) / DT_W, (ih + DT_H - 1) / DT_H, batch), dim3(256),
                                    0, st, T, o, thr, d_cand, cap, d_cnt, zs);

@@ -35,6 +35,7 @@ python3 "$root/tools/rocpd_stats.py" "$out"/kt_map/*/*_results.db "$out/map_extr
 python3 "$root/tools/rocpd_timeline.py" "$out"/kt_map/*/*_results.db 64 "$out/map_extract_timeline.md" > /dev/null || exit 1
 
 step pmc FETCH_SIZE
+export IMATCH_BENCH_SERIES=0     # the PMC passes need the headline workload only
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline \
     > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.err" || exit 1
 python3 "$root/tools/pmc_sum.py" "$out"/pmc_fetch/*/*_results.db "$out/pmc_fetch.md" > /dev/null || exit 1
@@ -45,6 +46,7 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -- python3 "$
 python3 "$root/tools/pmc_sum.py" "$out"/pmc_write/*/*_results.db "$out/pmc_write.md" > /dev/null || exit 1
 
 python3 "$root/tools/pmc_merge.py" "$out/pmc_fetch.md" "$out/pmc_write.md" "$out/bench.json" "$out/pmc.md" "$out/pmc_knn.json" || exit 1
+unset IMATCH_BENCH_SERIES
 
 step replay
 timeout -k 10 400 python3 "$root/tools/replay_c3.py" 240 8192 > "$out/replay_c3.json" 2> "$out/replay_c3.err" || exit 1

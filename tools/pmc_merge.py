@@ -4,11 +4,12 @@ Usage: pmc_merge.py pmc_fetch.md pmc_write.md bench.json out_pmc.md out_pmc_knn.
 import json
 import sys
 
-HEAD = """# PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of `bench.py --steps 2 --warmup 1 --no-cpu-baseline`, batch 64)
+HEAD = """# PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of `bench.py --steps 2 --warmup 1 --no-cpu-baseline`)
 
 FETCH_SIZE and WRITE_SIZE are in KB, mean per launch. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE tallies the 128-B requests of
-16-B-per-lane streaming reads at 64 B on gfx950, so for the kernels that read that way (blur_march f32 source, knn2) the
-corrected figure is 2 x FETCH_SIZE; other access widths (detect_stream: 4 B per lane) are uncalibrated. WRITE_SIZE is exact.
+16-B-per-lane streaming reads at 64 B on gfx950, so the corrected figure is 2 x FETCH_SIZE. The extremum scans read 4, 8 or 16 B per
+lane (detect_stream_kernel, detect_streamv_kernel<2>, <4>); tools/fetch_calib.hip reads a known 2 GiB in exactly those patterns and
+FETCH_SIZE reports half of it for all three (profiles/r3_fetch_calib.md), so the same factor applies to them. WRITE_SIZE is exact.
 A 16384^2 f32 layer is 1048576 KB.
 
 | kernel | grid (threads) | launches | FETCH_SIZE KB | 2 x FETCH MB | WRITE_SIZE KB |
@@ -35,9 +36,21 @@ def main():
             continue
         fk = f[(k, g)][1]
         wk = w.get((k, g), (0, float("nan")))[1]
-        cal = "(uncalibrated width)" if k.startswith("detect_stream") else "%.1f" % (2 * fk / 1024)
+        cal = "%.1f" % (2 * fk / 1024)
         rows.append("| %s | %d | %d | %.0f | %s | %.0f |" % (k, g, f[(k, g)][0], fk, cal, wk))
     open(sys.argv[4], "w").write(HEAD + "\n".join(rows) + "\n")
+    # the scale-space stage of the MAP extraction (bench.py extracts the map twice before anything else): its kernels'
+    # launches are the ones with the largest grids of each kernel name; per extraction = sum over kernels of
+    # (2 x FETCH + WRITE) of the launches that belong to the map, identified by launch count 2 (two extractions)
+    pyr = 0.0
+    for (k, g), (n, fk) in f.items():
+        if k.startswith(("blur_march_kernel", "detect_stream")) and n == 2:
+            pyr += (2 * fk + w.get((k, g), (0, 0.0))[1]) * 1024.0
+    json.dump({"traffic_bytes_per_extraction": pyr, "map_side": bench["roofline_pyramid"]["kernel"],
+               "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over bench.py; sum over the blur and "
+                         "scan launches that occur exactly twice (the two map extractions), 2 x FETCH + WRITE each; the small "
+                         "octaves' single-workgroup kernel is not in the sum (< 0.1 %)"},
+              open(sys.argv[5].replace("pmc_knn", "pmc_pyramid"), "w"), indent=1)
     # the dominant kNN launch = the batch's launch seen most often among the large grids
     knn = [(kg, v) for kg, v in f.items() if kg[0].startswith("knn2_kernel") and kg[1] > 1024 * 1024]
     (k, g), (n, fk) = max(knn, key=lambda kv: kv[1][0])
