@@ -48,6 +48,14 @@ python3 "$root/tools/pmc_sum.py" "$out"/pmc_write/*/*_results.db "$out/pmc_write
 python3 "$root/tools/pmc_merge.py" "$out/pmc_fetch.md" "$out/pmc_write.md" "$out/bench.json" "$out/pmc.md" "$out/pmc_knn.json" || exit 1
 unset IMATCH_BENCH_SERIES
 
+step pmc map extraction
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_mapf" -- python3 "$root/tools/extract_profile.py" 8192 2 > "$out/pmc_mapf.log" 2>&1 || exit 1
+python3 "$root/tools/pmc_sum.py" "$out"/pmc_mapf/*/*_results.db "$out/pmc_map_fetch.md" > /dev/null || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_mapw" -- python3 "$root/tools/extract_profile.py" 8192 2 > "$out/pmc_mapw.log" 2>&1 || exit 1
+python3 "$root/tools/pmc_sum.py" "$out"/pmc_mapw/*/*_results.db "$out/pmc_map_write.md" > /dev/null || exit 1
+python3 "$root/tools/pmc_pyramid.py" "$out/pmc_map_fetch.md" "$out/pmc_map_write.md" 8192 2 "$out/pmc_pyramid.json" "$out/pmc_pyramid.md" || exit 1
+rm -rf "$out"/pmc_mapf "$out"/pmc_mapw
+
 step replay
 timeout -k 10 400 python3 "$root/tools/replay_c3.py" 240 8192 > "$out/replay_c3.json" 2> "$out/replay_c3.err" || exit 1
 

@@ -15,7 +15,7 @@ A 16384^2 f32 layer is 1048576 KB.
 | kernel | grid (threads) | launches | FETCH_SIZE KB | 2 x FETCH MB | WRITE_SIZE KB |
 |---|---|---|---|---|---|
 """
-KEEP = ("detect_stream_kernel", "blur_march_kernel", "knn2_kernel")
+KEEP = ("detect_stream", "blur_march_kernel", "knn2_kernel")
 
 
 def table(path):
@@ -39,18 +39,6 @@ def main():
         cal = "%.1f" % (2 * fk / 1024)
         rows.append("| %s | %d | %d | %.0f | %s | %.0f |" % (k, g, f[(k, g)][0], fk, cal, wk))
     open(sys.argv[4], "w").write(HEAD + "\n".join(rows) + "\n")
-    # the scale-space stage of the MAP extraction (bench.py extracts the map twice before anything else): its kernels'
-    # launches are the ones with the largest grids of each kernel name; per extraction = sum over kernels of
-    # (2 x FETCH + WRITE) of the launches that belong to the map, identified by launch count 2 (two extractions)
-    pyr = 0.0
-    for (k, g), (n, fk) in f.items():
-        if k.startswith(("blur_march_kernel", "detect_stream")) and n == 2:
-            pyr += (2 * fk + w.get((k, g), (0, 0.0))[1]) * 1024.0
-    json.dump({"traffic_bytes_per_extraction": pyr, "map_side": bench["roofline_pyramid"]["kernel"],
-               "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over bench.py; sum over the blur and "
-                         "scan launches that occur exactly twice (the two map extractions), 2 x FETCH + WRITE each; the small "
-                         "octaves' single-workgroup kernel is not in the sum (< 0.1 %)"},
-              open(sys.argv[5].replace("pmc_knn", "pmc_pyramid"), "w"), indent=1)
     # the dominant kNN launch = the batch's launch seen most often among the large grids
     knn = [(kg, v) for kg, v in f.items() if kg[0].startswith("knn2_kernel") and kg[1] > 1024 * 1024]
     (k, g), (n, fk) = max(knn, key=lambda kv: kv[1][0])
