@@ -69,6 +69,8 @@ struct imatch_segtab { int n; int off[IMATCH_MAX_BATCH + 1]; };
 int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out);
 int imatch_features_pack_u8_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev);
 int imatch_features_pad_dev(imatch_ctx* ctx, imatch_features* f);   // rows n .. n_pad and the flag of a set whose rows a kernel wrote itself
+// ... when the row count is still on the device: rows *n_dev .. n_pad (the allocated capacity)
+int imatch_features_pad_counted_dev(imatch_ctx* ctx, imatch_features* f, const int* n_dev);
 // rows of image b are read from src_dev + b*zs (bytes) + (row - off[b])*128
 int imatch_features_pack_u8_seg_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev, const imatch_segtab* seg,
                                     size_t zs);

@@ -77,6 +77,10 @@ typedef int __attribute__((ext_vector_type(4))) i32x4;
 #define KNN_TILE_PAIRS 1   // 0: the one-tile main loop (kept for A/B builds)
 #endif
 
+#ifndef KNN_XM
+#define KNN_XM 7           // the large form exchanges bounds every KNN_XM + 1 stages once a chunk is no longer young
+#endif
+
 #define KNN_INF 0x7f7f7f7f            // "no bound yet" / an empty list slot (what hipMemset 0x7f leaves in a word)
 #define KNN_PAD_TNEG (-(1 << 24))     // T' of a pad row
 
@@ -678,6 +682,31 @@ int imatch_features_pad_dev(imatch_ctx* ctx, imatch_features* f) {
     return IMATCH_OK;
 }
 
+// The same for a set whose row count is still on the device when the launch is queued (a single frame's descriptors,
+// launched behind the sort before the host has seen its count): every row from *n_dev (a negative count reads as 0) up
+// to the set's allocated capacity becomes a pad row; the host sets f->n and f->n_pad once it knows the count.
+__global__ void pad_rows_counted_kernel(const int* __restrict__ n_dev, int64_t n_alloc, int8_t* __restrict__ dst,
+                                        int* __restrict__ norm, int* __restrict__ tneg, int* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;
+    if (row >= n_alloc || row < (int64_t)max(*n_dev, 0)) return;
+    ((uint16_t*)dst)[row * 64 + lane] = 0;
+    if (lane == 0) {
+        norm[row] = 0;
+        tneg[row] = KNN_PAD_TNEG;
+    }
+}
+
+int imatch_features_pad_counted_dev(imatch_ctx* ctx, imatch_features* f, const int* n_dev) {
+    const unsigned grid = (unsigned)((f->n_pad + 3) / 4);
+    hipLaunchKernelGGL(pad_rows_counted_kernel, dim3(grid), dim3(256), 0, ctx->stream, n_dev, f->n_pad, f->desc, f->norm,
+                       f->tneg, f->flag);
+    HIP_TRY(ctx, hipGetLastError());
+    f->integral = 1;
+    return IMATCH_OK;
+}
+
 // u8 rows are integral by type: no flag to read back, so this only queues work on the stream
 int imatch_features_pack_u8_dev(imatch_ctx* ctx, imatch_features* f, const uint8_t* src_dev) {
     HIP_TRY(ctx, hipMemsetAsync(f->flag, 0, 256, ctx->stream));
@@ -839,7 +868,7 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
         else if (TNs == 256)
             hipLaunchKernelGGL((knn2_kernel8<8, 256, 7>), dim3(grid), dim3(256), dyn, ctx->stream, KARGS);
         else
-            hipLaunchKernelGGL((knn2_kernel8<8, 128, 7>), dim3(grid), dim3(256), dyn, ctx->stream, KARGS);
+            hipLaunchKernelGGL((knn2_kernel8<8, 128, KNN_XM>), dim3(grid), dim3(256), dyn, ctx->stream, KARGS);
 #undef KARGS
     }
     HIP_TRY(ctx, hipGetLastError());

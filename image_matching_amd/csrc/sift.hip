@@ -88,11 +88,13 @@ struct imatch_sift_state {
     hipEvent_t ev_sorted;
     // the one-workgroup-per-octave form of the small-octave kernel once timed out on this context: it is not used again
     bool no_tail_split;
+    hipEvent_t ev_counts;   // recorded behind the count / record copies of a single frame (the descriptor launches follow it)
 };
 
 void imatch_sift_state_free(imatch_ctx* ctx) {
     if (!ctx || !ctx->sift) return;
     if (ctx->sift->arena) (void)hipFree(ctx->sift->arena);
+    if (ctx->sift->ev_counts) (void)hipEventDestroy(ctx->sift->ev_counts);
     if (ctx->sift->copy) {
         (void)hipStreamSynchronize(ctx->sift->copy);
         (void)hipEventDestroy(ctx->sift->ev_sorted);
@@ -1104,11 +1106,15 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
 template <int WPK>
 __global__ void __launch_bounds__(256)
 describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first_octave, int8_t* __restrict__ rows_i8,
-                int* __restrict__ norm, int* __restrict__ tneg, size_t zs) {
+                int* __restrict__ norm, int* __restrict__ tneg, size_t zs, const int* __restrict__ n_dev) {
     const size_t zo = (size_t)blockIdx.z * zs;
     kps = ZP(kps);
-    const int n_kp = seg.off[blockIdx.z + 1] - seg.off[blockIdx.z];
+    int n_kp = seg.off[blockIdx.z + 1] - seg.off[blockIdx.z];
+    // n_dev: the launch was queued BEFORE the host knew the image's keypoint count (a single frame: the segment is the
+    // list's capacity); the count is the sort kernel's, read where it lies (-1: the sort left the list to the host)
+    if (n_dev) n_kp = min(n_kp, *ZP(n_dev));
     constexpr int GROUPS = 4 / WPK, GL = 64 * WPK;
+    if ((int)blockIdx.x * GROUPS >= n_kp) return;   // workgroup-uniform
     __shared__ unsigned long long hist[GROUPS][DESC_HIST];
     __shared__ unsigned queue[4][128];   // per wave: indices of samples inside the rotated grid, waiting for a full wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x / GL, gl = threadIdx.x % GL;
@@ -1679,7 +1685,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         // kernel's read and write streams (row y of layer i, row y of layer i+1; the scan's six layers) sit on the
         // same HBM channels at every instant (tools/blur_bench.hip `pipe`: R = 13 0.83 ms -> 0.68 ms with the gap;
         // inside the extraction the effect is within run-to-run noise, the gap costs 6 MB per octave).
-        const size_t stagger = px >= ((size_t)16 << 20) ? (size_t)1057024 : 0;
+        const size_t stagger = px >= ((size_t)16 << 20) ? (size_t)1057024 : 0;   // (a stagger on frame-sized layers changes nothing: profiles/r3_small_experiments.txt)
         for (int i = 0; i < nl + 3; ++i) { o_g[o][i] = take(px); (void)take(stagger); }
     }
     T.n_oct = n_oct;
@@ -1997,6 +2003,16 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             HIP_TRY(ctx, hipGetLastError());
         }
         (void)imatch_stage_end(ctx, IMATCH_STAGE_KEYPOINTS, ctx->stream);
+        // ---- A single frame sorted on the device: its descriptors are queued before the host has seen a count (behind the copies below). The
+        // set is allocated for as many rows as the sort was launched for (the frame's keypoints are at most that many, or
+        // the sort reports -1 and the launch does nothing), the kernels read the count where the sort left it, and the
+        // host fixes the set's row count after the synchronisation. The GPU used to idle from the end of the sort to the
+        // host's launch (the synchronisation's wake-up, the set's allocation, the launch: 35-45 us of a 0.65 ms frame).
+        static const int spec_env = getenv("IMATCH_SIFT_SPECDESC") ? atoi(getenv("IMATCH_SIFT_SPECDESC")) : 1;
+        struct SpecSet {   // freed on every way out on which nobody took it over
+            imatch_features* f;
+            ~SpecSet() { if (f) imatch_features_free(f); }
+        } spec{nullptr};
         // ---- the extraction's one synchronisation: the counters and (a guess of) the records of every image
         int kp_hint = std::min(2 * cap, S->kp_hint > 0 ? S->kp_hint : 8192);
         if (dev_sort) kp_hint = std::min(kp_hint, SORT_CAP);
@@ -2031,10 +2047,31 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), dev_sort ? d_sorted : d_kp, zs,
                                           (size_t)kp_hint * sizeof(KpRec), (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
         }
+        // the host waits for the copies only: the descriptor launches queued behind them run while it sorts out the counts
+        bool wait_on_event = false;
+        if (spec_env && batch == 1 && dev_sort && S->kp_hint > 0 && !copy_aside) {
+            if (!S->ev_counts) HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_counts, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(S->ev_counts, ctx->stream));
+            wait_on_event = true;
+            rc = imatch_features_alloc(ctx, n_sort, &spec.f);
+            if (rc) return rc;
+            SegTab seg1;
+            memset(&seg1, 0, sizeof(seg1));
+            seg1.n = 1;
+            seg1.off[1] = n_sort;
+            (void)imatch_stage_begin(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
+            hipLaunchKernelGGL(describe_kernel<4>, dim3(n_sort, 1, 1), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted, seg1,
+                               first_octave, spec.f->desc, spec.f->norm, spec.f->tneg, zs, (const int*)(d_cnt + 3));
+            HIP_TRY(ctx, hipGetLastError());
+            (void)imatch_stage_end(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
+            rc = imatch_features_pad_counted_dev(ctx, spec.f, d_cnt + 3);
+            if (rc) return rc;
+        }
         const bool timing = getenv("IMATCH_TIMING") != nullptr;
         const double t_a = now_ms();
         DBG_STEP("chain queued: sync for the counts");
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (wait_on_event) HIP_TRY(ctx, hipEventSynchronize(S->ev_counts));
+        else HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         DBG_STEP("counts are here");
         const double t_b = now_ms();
         int max_cand = 0, max_ref = 0, max_kp = 0, timed_out = 0;
@@ -2141,8 +2178,18 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         }
         const int Ktot = seg.off[batch];
         imatch_features* f = nullptr;
-        rc = imatch_features_alloc(ctx, Ktot, &f);
-        if (rc) return rc;
+        // the set queued before the synchronisation holds this frame's rows if the sort ran (dev_sort still true) --
+        // Ktot <= n_sort then; its pad rows start at Ktot, so the kNN's row padding is the usual multiple of 1024
+        const bool spec_ok = spec.f && dev_sort && Ktot <= (int)spec.f->n;
+        if (spec_ok) {
+            f = spec.f;
+            spec.f = nullptr;
+            f->n = Ktot;
+            f->n_pad = std::max<int64_t>(((int64_t)Ktot + IMATCH_ROW_PAD - 1) / IMATCH_ROW_PAD * IMATCH_ROW_PAD, IMATCH_ROW_PAD);
+        } else {
+            rc = imatch_features_alloc(ctx, Ktot, &f);
+            if (rc) return rc;
+        }
         f->kp = (float*)malloc(sizeof(float) * 7 * (size_t)std::max(Ktot, 1));
         auto fill_table = [&](int b) {
             const KpRec* rec = h_kp + (size_t)b * kp_hint;
@@ -2175,7 +2222,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             cap = (int)((size_t)max_k * 3 + 1024);
             continue;
         }
-        if (Ktot > 0) {
+        if (Ktot > 0 && !spec_ok) {
             // this copy is still reading the pinned rows when the call returns: the next writer of ctx->hs waits for it
             // (imatch_hs_reserve)
             if (!dev_sort) {
@@ -2193,19 +2240,21 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             (void)imatch_stage_begin(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
             if (wpk == 4)
                 hipLaunchKernelGGL(describe_kernel<4>, dim3(max_k, 1, batch), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted,
-                                   seg, first_octave, f->desc, f->norm, f->tneg, zs);
+                                   seg, first_octave, f->desc, f->norm, f->tneg, zs, (const int*)nullptr);
             else if (wpk == 2)
                 hipLaunchKernelGGL(describe_kernel<2>, dim3((max_k + 1) / 2, 1, batch), dim3(256), 0, ctx->stream, T,
-                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs);
+                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs, (const int*)nullptr);
             else
                 hipLaunchKernelGGL(describe_kernel<1>, dim3((max_k + 3) / 4, 1, batch), dim3(256), 0, ctx->stream, T,
-                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs);
+                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs, (const int*)nullptr);
             HIP_TRY(ctx, hipGetLastError());
             (void)imatch_stage_end(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
         }
         // the set's pad rows and flag (u8 rows are integral by type)
-        rc = imatch_features_pad_dev(ctx, f);   // the rows themselves came from describe_kernel
-        if (rc) { imatch_features_free(f); return rc; }
+        if (!spec_ok) {
+            rc = imatch_features_pad_dev(ctx, f);   // the rows themselves came from describe_kernel
+            if (rc) { imatch_features_free(f); return rc; }
+        }
         // the host copy of the keypoint table is written while the GPU works on the descriptors (it reads the pinned rows
         // the upload queued above is reading too)
         {
