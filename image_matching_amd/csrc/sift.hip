@@ -1822,7 +1822,8 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             const int iw = cols - 2 * SIFT_IMG_BORDER, ih = rows - 2 * SIFT_IMG_BORDER;
             if (nl == 3) {
                 const size_t px = (size_t)iw * ih * batch;
-                const int rpw = px >= ((size_t)1 << 26) ? 64 : px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
+                static const int rpw_env = getenv("IMATCH_SIFT_RPW") ? atoi(getenv("IMATCH_SIFT_RPW")) : 0;   // experiments
+                const int rpw = rpw_env > 0 ? rpw_env : px >= ((size_t)1 << 26) ? 64 : px >= ((size_t)1 << 24) ? 32 : px >= ((size_t)1 << 20) ? 16 : 8;
                 // columns per lane (profiles/r3_scanv_sweep.txt): 4 on the 32768^2 layers of a 16384^2 map (scale space 25.1 ->
                 // 22.6 ms; 24.1 with 2), 2 elsewhere (8192^2 map 6.43 -> 6.11 ms; 6.26 with 4: fewer waves per SIMD), 1 where
                 // the rows are odd or narrower than a strip (IMATCH_SIFT_SCANV = 1 / 2 / 4 forces a form where it is possible)

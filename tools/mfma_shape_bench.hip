@@ -147,6 +147,79 @@ loop32(const uint4* __restrict__ Q, const uint4* __restrict__ T, const int* __re
     if (hits == 0x12345678) sink[threadIdx.x] = hits;
 }
 
+
+// ---- 16x16x64 on QUADS of tiles: four 16-row tiles per step, 16 results per lane and query block, one max tree, one
+// compare, one branch per eight MFMAs; DB = 1 keeps two accumulator sets (the next block's chains are out before this
+// block's epilogue), DB = 0 one set (fewer registers: a fourth workgroup per CU with QB = 6) -------------------------------
+template <int QB, int DB, int WGS>
+__global__ void __launch_bounds__(256, WGS)
+loop16q(const uint4* __restrict__ Q, const uint4* __restrict__ T, const int* __restrict__ Gq, int iters, int* __restrict__ sink) {
+    __shared__ uint4 lds[39936 / 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    for (int i = threadIdx.x; i < STAGE_BYTES / 16; i += 256) lds[i] = T[(blockIdx.x % 61) * (STAGE_BYTES / 16) + i];
+    i32x4 qf[QB][2];
+    int G[QB];
+    const size_t qrow0 = ((size_t)blockIdx.x * 4 + wave) * (16 * QB);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) qf[qb][t] = __builtin_bit_cast(i32x4, Q[((qrow0 + qb * 16 + r) * 8 + 4 * t + q) & 0xfffff]);
+        G[qb] = Gq[(qrow0 + qb * 16 + r) & 0xffff];
+    }
+    __syncthreads();
+    const unsigned frag_off = (lane & 15) * 128u + ((((lane >> 4) ^ lane) & 7) << 4);
+    int hits = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+        for (int tq = 0; tq < TN / 64; ++tq) {
+            i32x4 af[4][2], tin[4];
+            const unsigned a0 = (unsigned)tq * 8192u + frag_off;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    af[u][t] = __builtin_bit_cast(i32x4, *(const uint4*)((const char*)lds + ((a0 + 2048u * u) ^ (unsigned)(t << 6))));
+                tin[u] = __builtin_bit_cast(i32x4, lds[TN * 8 + tq * 16 + 4 * u + q]) >> 1;
+            }
+            i32x4 P[DB ? 2 : 1][4];
+            auto chain4 = [&](int qb, i32x4 (&x)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u][0], qf[qb][0], tin[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u][1], qf[qb][1], x[u], 0, 0, 0);
+            };
+            auto epi = [&](const i32x4 (&x)[4], int qb) {
+                int m = x[0][0];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) m = max(m, x[u][g]);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= G[qb]) != 0, 0)) {
+                    hits += x[0][0] + x[3][3];
+                    G[qb] += 1;
+                }
+            };
+            if (DB) {
+                chain4(0, P[0]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    const int cs = qb & 1, ns = cs ^ 1;
+                    if (qb + 1 < QB) chain4(qb + 1, P[ns]);
+                    epi(P[cs], qb);
+                }
+            } else {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    chain4(qb, P[0]);
+                    epi(P[0], qb);
+                }
+            }
+        }
+    }
+    if (hits == 0x12345678) sink[threadIdx.x] = hits;
+}
+
 static double run(const char* name, void (*launch)(int, int, hipStream_t), double ops_per_wg_iter, int grid, int iters) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -174,6 +247,11 @@ static int *dG, *dS;
 LAUNCHER(l16_e1_3, (loop16<8, 1, 3>))
 LAUNCHER(l16_e0_3, (loop16<8, 0, 3>))
 LAUNCHER(l16_e1_2, (loop16<8, 1, 2>))
+LAUNCHER(l16q8_db_2, (loop16q<8, 1, 2>))
+LAUNCHER(l16q8_sb_3, (loop16q<8, 0, 3>))
+LAUNCHER(l16q6_db_3, (loop16q<6, 1, 3>))
+LAUNCHER(l16q6_sb_4, (loop16q<6, 0, 4>))
+LAUNCHER(l16q6_sb_3, (loop16q<6, 0, 3>))
 LAUNCHER(l32_e1_2, (loop32<4, 1, 2>))
 LAUNCHER(l32_e0_2, (loop32<4, 0, 2>))
 LAUNCHER(l32_e1_3, (loop32<4, 1, 3>))
@@ -212,6 +290,11 @@ int main(int argc, char** argv) {
     run("16x16x64 pairs, epilogue, 3 wg/CU", l16_e1_3, 4.0 * 128 * TN * 256, 768 * 2, iters);
     run("16x16x64 pairs, no epilogue, 3 wg/CU", l16_e0_3, 4.0 * 128 * TN * 256, 768 * 2, iters);
     run("16x16x64 pairs, epilogue, 2 wg/CU", l16_e1_2, 4.0 * 128 * TN * 256, 512 * 2, iters);
+    run("16x16x64 quads QB8 2 sets, 2 wg/CU", l16q8_db_2, 4.0 * 128 * TN * 256, 512 * 2, iters);
+    run("16x16x64 quads QB8 1 set, 3 wg/CU", l16q8_sb_3, 4.0 * 128 * TN * 256, 768 * 2, iters);
+    run("16x16x64 quads QB6 2 sets, 3 wg/CU", l16q6_db_3, 4.0 * 96 * TN * 256, 768 * 2, iters);
+    run("16x16x64 quads QB6 1 set, 3 wg/CU", l16q6_sb_3, 4.0 * 96 * TN * 256, 768 * 2, iters);
+    run("16x16x64 quads QB6 1 set, 4 wg/CU", l16q6_sb_4, 4.0 * 96 * TN * 256, 1024 * 2, iters);
     run("32x32x32 QB4, epilogue, 2 wg/CU", l32_e1_2, 4.0 * 128 * TN * 256, 512 * 2, iters);
     run("32x32x32 QB4, no epilogue, 2 wg/CU", l32_e0_2, 4.0 * 128 * TN * 256, 512 * 2, iters);
     run("32x32x32 QB4, epilogue, 3 wg/CU", l32_e1_3, 4.0 * 128 * TN * 256, 768 * 2, iters);
