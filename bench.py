@@ -178,7 +178,7 @@ def akaze_extra(ctx, map_img, ratio):
 
         def one(f, i):
             kp, desc = ctx.akaze_extract(f, p)
-            idx, dist = ctx.knn2_f32(desc, cset)
+            idx, dist = ctx.knn2_fset_akaze(ctx.akaze_last()[0], cset)     # the frame's descriptors where the extraction left them
             keep = dist[:, 0].astype(np.float64) < ratio * dist[:, 1].astype(np.float64)
             q = np.nonzero(keep)[0]
             H = None
@@ -199,8 +199,9 @@ def akaze_extra(ctx, map_img, ratio):
                 "ms_per_frame": ms, "frames_per_s": 1e3 / ms, "keypoints_per_frame": n_kp / (reps * len(frames)),
                 "crop": "2048x2048, %d keypoints, extracted in %.1f ms" % (len(ckp), t_crop * 1e3),
                 "homographies_found": "%d/%d" % (found, reps * len(frames)),
-                "note": "single-frame calls with host pointers in and out (imatch_akaze_extract, imatch_knn2_fset against the "
-                        "resident crop set, imatch_homography), measured after the timed region; not part of value"}
+                "note": "single-frame calls (imatch_akaze_extract with host pointers in and out, imatch_knn2_fset_akaze: the frame's "
+                        "descriptors matched where the extraction left them against the resident crop set, imatch_homography), "
+                        "measured after the timed region; not part of value"}
     except Exception as e:      # must not take the headline down with it
         return {"error": repr(e)[:300]}
 

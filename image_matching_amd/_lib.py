@@ -88,6 +88,8 @@ SIGNATURES = {
     "imatch_fset_count": (c_i64, [c_vp]),
     "imatch_fset_free": (None, [c_vp]),
     "imatch_knn2_fset": (ctypes.c_int, [c_vp, c_f32p, c_i64, c_vp, c_i32p, c_f32p]),
+    "imatch_akaze_last": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i64)]),
+    "imatch_knn2_fset_akaze": (ctypes.c_int, [c_vp, ctypes.c_uint64, c_vp, c_i32p, c_f32p]),
     "imatch_akaze_extract": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.POINTER(AkazeParams), ctypes.POINTER(c_i64)]),
     "imatch_akaze_extract_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -544,6 +546,25 @@ class Context:
         with self.lock:
             self._check(self.lib.imatch_knn2_f32(self._h, _ptr(q, c_f32p), len(q), _ptr(t, c_f32p), len(t), d,
                                                  _ptr(idx, c_i32p), _ptr(dist, c_f32p)))
+        return idx, dist
+
+    def akaze_last(self):
+        """(serial, n) of this context's last AKAZE extraction, whose descriptors are still on the device; serial 0: none."""
+        serial, n = ctypes.c_uint64(0), c_i64(0)
+        with self.lock:
+            self._check(self.lib.imatch_akaze_last(self._h, ctypes.byref(serial), ctypes.byref(n)))
+        return int(serial.value), int(n.value)
+
+    def knn2_fset_akaze(self, serial, t):
+        """knn2_f32 with the descriptors of AKAZE extraction `serial` as the queries, taken where the extraction left
+        them on the device (no download / upload round trip), against the resident set t. Raises ImatchError when the
+        context has run another AKAZE extraction since."""
+        _, n = self.akaze_last()
+        idx = np.empty((n, 2), np.int32)
+        dist = np.empty((n, 2), np.float32)
+        with self.lock:
+            self._check(self.lib.imatch_knn2_fset_akaze(self._h, ctypes.c_uint64(int(serial)), t._h, _ptr(idx, c_i32p),
+                                                        _ptr(dist, c_f32p)))
         return idx, dist
 
     def akaze_extract_dev(self, img_ptr, h, w, stride, params=None):

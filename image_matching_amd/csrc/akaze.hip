@@ -64,6 +64,7 @@ struct imatch_akaze_state {
     // last result (host)
     std::vector<float> kp, desc;
     int n_kp;
+    uint64_t serial;         // number of the extraction whose descriptors sit in desc_dev (0: none); see imatch_akaze_last
 };
 
 void imatch_akaze_state_free(imatch_ctx* ctx) {
@@ -1285,6 +1286,7 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     const auto t_filter = now();
     const int n = (int)(kdev.size() / 8);
     S->n_kp = n;
+    S->serial = 0;   // desc_dev is about to be rewritten (or the lists regrown): no extraction's descriptors are there until the end
     S->kp.assign((size_t)n * 7, 0.f);
     S->desc.assign((size_t)n * 64, 0.f);
     if (n == 0) return IMATCH_OK;
@@ -1313,6 +1315,8 @@ static int akaze_run(imatch_ctx* ctx, const uint8_t* img_dev, int h, int w, int 
     memcpy(kdev.data(), ctx->hs, kb);
     memcpy(S->desc.data(), (char*)ctx->hs + kb, db);
     for (int i = 0; i < n; ++i) memcpy(S->kp.data() + (size_t)i * 7, kdev.data() + (size_t)i * 8, 28);
+    static uint64_t next_serial = 0;   // process-wide: a serial names one extraction on whatever context
+    S->serial = __atomic_add_fetch(&next_serial, 1, __ATOMIC_RELAXED);
     if (timing)
         fprintf(stderr, "[imatch] akaze host phases: wait for GPU %.3f ms, candidates down %.3f ms (%d), filter + sub-pixel %.3f ms, "
                 "orientation + descriptors + download %.3f ms (%d)\n", ms(t_enq, t_gpu), ms(t_gpu, t_dl), n_cand, ms(t_dl, t_filter),
@@ -1352,6 +1356,20 @@ int imatch_akaze_download(imatch_ctx* ctx, float* kp, float* desc) {
     const imatch_akaze_state* S = ctx->akaze;
     if (kp && S->n_kp) memcpy(kp, S->kp.data(), (size_t)S->n_kp * 7 * 4);
     if (desc && S->n_kp) memcpy(desc, S->desc.data(), (size_t)S->n_kp * 64 * 4);
+    return IMATCH_OK;
+}
+
+int imatch_akaze_last(imatch_ctx* ctx, uint64_t* serial, int64_t* n) {
+    if (!ctx || !serial) return imatch_set_err(ctx, IMATCH_EINVAL, "null argument");
+    *serial = (ctx->akaze && ctx->akaze->n_kp > 0) ? ctx->akaze->serial : 0;
+    if (n) *n = *serial ? ctx->akaze->n_kp : 0;
+    return IMATCH_OK;
+}
+
+int imatch_akaze_last_dev(imatch_ctx* ctx, uint64_t serial, const float** desc_dev, int64_t* n) {
+    if (!ctx || !ctx->akaze || serial == 0 || ctx->akaze->serial != serial || ctx->akaze->n_kp <= 0) return IMATCH_EINVAL;
+    *desc_dev = ctx->akaze->desc_dev;
+    *n = ctx->akaze->n_kp;
     return IMATCH_OK;
 }
 

@@ -79,6 +79,9 @@ int imatch_knn2_scratch_setup(imatch_ctx* ctx);
 void imatch_sift_state_free(imatch_ctx* ctx);
 void imatch_camera_state_free(imatch_ctx* ctx);
 void imatch_akaze_state_free(imatch_ctx* ctx);
+// the descriptors [n][64] of the AKAZE extraction `serial`, where the extraction left them on the device; IMATCH_EINVAL
+// (no error text) when the context's last extraction is another one
+extern "C" int imatch_akaze_last_dev(imatch_ctx* ctx, uint64_t serial, const float** desc_dev, int64_t* n);
 int imatch_set_err(imatch_ctx* ctx, int code, const char* fmt, ...);
 // Stage brackets (core.hip): with profiling on, an event on `st` and a roctx range (when libroctx64 is loadable) at both
 // ends of a stage; nothing otherwise. Return a hipError_t-free int: IMATCH_OK or IMATCH_EHIP with the message set.

@@ -124,9 +124,10 @@ struct imatch_fset {
     int d;
 };
 
-// q_host [nq][d] is uploaded; the train rows are either uploaded too (t_host) or already resident (t_dev)
+// q_host [nq][d] is uploaded, or the queries are already on the device (q_dev); the train rows are either uploaded too
+// (t_host) or already resident (t_dev)
 static int knn2_f32_run(imatch_ctx* ctx, const float* q_host, int64_t nq, const float* t_host, const float* t_dev, int64_t nt, int d,
-                        int32_t* idx, float* dist) {
+                        int32_t* idx, float* dist, const float* q_dev = nullptr) {
     if (nq > INT32_MAX / 2 || nt > INT32_MAX / 2) return imatch_set_err(ctx, IMATCH_ESIZE, "set too large");
     if (nq == 0) return IMATCH_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -137,12 +138,13 @@ static int knn2_f32_run(imatch_ctx* ctx, const float* q_host, int64_t nq, const 
     const int tiles_per_chunk = (int)std::max<int64_t>(1, (n_tiles + n_chunks - 1) / n_chunks);
     n_chunks = (int)std::max<int64_t>(1, (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t bq = up((size_t)nq * d * 4), bt = t_host ? up((size_t)std::max<int64_t>(nt, 1) * d * 4) : 0;
+    const size_t bq = q_dev ? 0 : up((size_t)nq * d * 4), bt = t_host ? up((size_t)std::max<int64_t>(nt, 1) * d * 4) : 0;
     const size_t bp = up((size_t)n_chunks * nq * sizeof(kf_top2)), bi = up((size_t)nq * 8), bd = up((size_t)nq * 8);
     int rc = imatch_ws_reserve(ctx, bq + bt + bp + bi + bd);
     if (rc) return rc;
     char* p = (char*)ctx->ws;
-    float* qd = (float*)p; p += bq;
+    const float* qd = q_dev ? q_dev : (const float*)p;
+    float* q_up = (float*)p; p += bq;
     const float* td = t_host ? (const float*)p : t_dev;
     p += bt;
     kf_top2* part = (kf_top2*)p; p += bp;
@@ -150,9 +152,10 @@ static int knn2_f32_run(imatch_ctx* ctx, const float* q_host, int64_t nq, const 
     float* dist_d = (float*)p;
     rc = imatch_hs_reserve(ctx, bq + bt + bi + bd);
     if (rc) return rc;
-    memcpy(ctx->hs, q_host, (size_t)nq * d * 4);
+    if (!q_dev) memcpy(ctx->hs, q_host, (size_t)nq * d * 4);
     if (t_host && nt) memcpy((char*)ctx->hs + bq, t_host, (size_t)nt * d * 4);
-    HIP_TRY(ctx, hipMemcpyAsync(qd, ctx->hs, bq + ((t_host && nt) ? (size_t)nt * d * 4 : 0), hipMemcpyHostToDevice, ctx->stream));
+    const size_t up_bytes = bq + ((t_host && nt) ? (size_t)nt * d * 4 : 0);
+    if (up_bytes) HIP_TRY(ctx, hipMemcpyAsync(q_up, ctx->hs, up_bytes, hipMemcpyHostToDevice, ctx->stream));
     const size_t lds = std::max((size_t)2 * d * 64 * 4, (size_t)64 * 16 * sizeof(kf_top2));
     hipLaunchKernelGGL(knn2_f32_kernel, dim3(q_tiles, n_chunks), dim3(256), lds, ctx->stream, qd, nq, td, nt, d, tiles_per_chunk, part);
     hipLaunchKernelGGL(knn2_f32_finish_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream, part, n_chunks, nq,
@@ -212,6 +215,17 @@ void imatch_fset_free(imatch_fset* f) {
     if (!f) return;
     imatch_pool_free(f->ctx, f->desc);
     free(f);
+}
+
+int imatch_knn2_fset_akaze(imatch_ctx* ctx, uint64_t serial, const imatch_fset* t, int32_t* idx, float* dist) {
+    if (!ctx || !t || t->ctx != ctx || !idx || !dist) return imatch_set_err(ctx, IMATCH_EINVAL, "bad argument");
+    const float* qd = nullptr;
+    int64_t nq = 0;
+    if (imatch_akaze_last_dev(ctx, serial, &qd, &nq) != IMATCH_OK)
+        return imatch_set_err(ctx, IMATCH_EINVAL, "AKAZE extraction %llu is not this context's last one: its descriptors are no "
+                              "longer on the device (use imatch_knn2_fset with the host matrix)", (unsigned long long)serial);
+    if (t->d != 64) return imatch_set_err(ctx, IMATCH_EINVAL, "train set has %d-float rows, AKAZE's descriptors have 64", t->d);
+    return knn2_f32_run(ctx, nullptr, nq, nullptr, t->desc, t->n, t->d, idx, dist, qd);
 }
 
 int imatch_knn2_fset(imatch_ctx* ctx, const float* q, int64_t nq, const imatch_fset* t, int32_t* idx, float* dist) {

@@ -130,10 +130,14 @@ class FloatDescriptors(np.ndarray):
     handle of its copy in HBM, made the first time the matrix serves as the train side of find_matches; the ROI's
     descriptors are matched against for up to 11 frames (position_finder.py:232-240) and travel once."""
 
-    def __new__(cls, a):
+    def __new__(cls, a, source=None):
         obj = np.ascontiguousarray(a, dtype=np.float32).view(cls)
         obj.fset = None
+        # (context, serial) of the AKAZE extraction that produced this matrix: while it is the context's last extraction
+        # its descriptors are still on the device and the query side of find_matches takes them there
+        obj.source = source
         return obj
 
     def __array_finalize__(self, obj):
         self.fset = None      # slices and copies are new matrices
+        self.source = None

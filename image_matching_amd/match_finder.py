@@ -168,7 +168,7 @@ class match_finder():
         if self.detector == "akaze":
             rec, desc, out = self.ctx.akaze_extract(img, AkazeParams(self.akaze_threshold, self.akaze_octaves,
                                                                      self.akaze_layers, clahe=True), image=True)
-            return KeyPoints(rec), FloatDescriptors(desc), out
+            return KeyPoints(rec), FloatDescriptors(desc, source=(self.ctx, self.ctx.akaze_last()[0])), out
         f = self.ctx.sift_extract(img, self.sift_params(clahe=True))
         kp = KeyPoints(f.download(descriptors=False)[0])
         return kp, DeviceDescriptors(f), f.image(img.shape[0], img.shape[1])
@@ -180,6 +180,12 @@ class match_finder():
             if isinstance(train_dp, FloatDescriptors) and len(train_dp) > 0:
                 if train_dp.fset is None or train_dp.fset.ctx is not self.ctx or train_dp.fset._h is None:
                     train_dp.fset = self.ctx.fset(train_dp)
+                # the frame extracted last (position_finder.py:202-203 then 232-240): its descriptors are still where
+                # the extraction left them on the device
+                src = getattr(query_dp, "source", None)
+                if src is not None and src[0] is self.ctx and src[1] and train_dp.fset.d == 64 and \
+                        self.ctx.akaze_last() == (src[1], len(query_dp)):
+                    return self.ctx.knn2_fset_akaze(src[1], train_dp.fset)
                 return self.ctx.knn2_f32(query_dp, train_dp.fset)
             return self.ctx.knn2_f32(query_dp, train_dp)
         fq, ft = _features_of(self.ctx, query_dp), _features_of(self.ctx, train_dp)

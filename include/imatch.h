@@ -266,6 +266,14 @@ int imatch_fset_from_host(imatch_ctx* ctx, const float* desc, int64_t n, int d, 
 int64_t imatch_fset_count(const imatch_fset* f);
 void imatch_fset_free(imatch_fset* f);
 int imatch_knn2_fset(imatch_ctx* ctx, const float* q, int64_t nq, const imatch_fset* t, int32_t* idx, float* dist);
+/* The frame's side of the same call without the round trip: the reference hands find_matches the descriptor matrix
+ * find_kp_dp has just returned (PF:202-203, 232-240 -> MF:182-183), and after imatch_akaze_extract that matrix is still
+ * on the device. imatch_akaze_last names the context's last AKAZE extraction (*serial, 0 if there is none or it found no
+ * keypoint; *n its keypoints, may be null); imatch_knn2_fset_akaze matches THAT extraction's descriptors, where they
+ * lie, against a resident set: idx/dist [n][2] as imatch_knn2_fset gives them for the downloaded matrix, bit for bit.
+ * IMATCH_EINVAL when another extraction has run on the context since (the caller then uploads its host copy). */
+int imatch_akaze_last(imatch_ctx* ctx, uint64_t* serial, int64_t* n);
+int imatch_knn2_fset_akaze(imatch_ctx* ctx, uint64_t serial, const imatch_fset* t, int32_t* idx, float* dist);
 /* Merge step after the all-gather of per-shard top-2 (no reference counterpart: the reference is
  * single-process). in4_dev is int32 [n_lists][Q][4]; picks the two smallest by
  * (ssd, idx) lexicographic order into out4_dev [Q][4]. */

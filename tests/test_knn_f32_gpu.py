@@ -38,6 +38,45 @@ def test_resident_train_set(ctx):
     assert (gi == -1).all() and np.isinf(gd).all()
 
 
+def test_last_akaze_extraction_matched_where_it_lies(ctx):
+    """imatch_knn2_fset_akaze: the queries are the descriptors the last AKAZE extraction left on the device -- the
+    result equals the call that uploads the downloaded matrix, bit for bit; a later extraction retires the serial, and
+    the facade (match_finder.knn_match, match_finder.py:182-183) then takes the upload path by itself."""
+    import image_matching_amd as im
+    from image_matching_amd import synth
+    from image_matching_amd.match_finder import match_finder
+    from image_matching_amd.cvtypes import FloatDescriptors
+    img = synth.synth_map(1024, seed=5)
+    crop = np.ascontiguousarray(img[:768, :768])
+    frame = np.ascontiguousarray(img[100:580, 200:840])
+    p = im.AkazeParams()
+    ckp, cdesc = ctx.akaze_extract(crop, p)
+    fs = ctx.fset(cdesc)
+    kp, desc = ctx.akaze_extract(frame, p)
+    serial, n = ctx.akaze_last()
+    assert serial != 0 and n == len(kp) > 100
+    gi, gd = ctx.knn2_fset_akaze(serial, fs)
+    wi, wd = ctx.knn2_f32(desc, fs)
+    assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+    oi, od = oracle.knn2(desc, cdesc)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    ctx.akaze_extract(crop, p)                       # another extraction: the frame's descriptors are gone from the device
+    assert ctx.akaze_last()[0] != serial
+    with pytest.raises(im.ImatchError):
+        ctx.knn2_fset_akaze(serial, fs)
+    # the facade: device path while the frame is the last extraction, upload path afterwards -- same matches either way
+    mf = match_finder(ctx=ctx, detector="akaze")
+    rkp, rdp, _ = mf.find_kp_dp(crop)
+    fkp, fdp, _ = mf.find_kp_dp(frame)
+    assert isinstance(fdp, FloatDescriptors) and fdp.source is not None and fdp.source[1] == ctx.akaze_last()[0]
+    a = mf.knn_match(fdp, rdp)                        # device path
+    mf.find_kp_dp(crop)                               # retires the frame's serial
+    b = mf.knn_match(fdp, rdp)                        # upload path
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[0], oi) and np.array_equal(a[1], od)
+    fs.free()
+
+
 def test_empty_and_ties(ctx):
     q = _unit(10, 64, 1)
     gi, gd = ctx.knn2_f32(q, np.zeros((0, 64), np.float32))
