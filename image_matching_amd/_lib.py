@@ -88,6 +88,7 @@ SIGNATURES = {
     "imatch_fset_count": (c_i64, [c_vp]),
     "imatch_fset_free": (None, [c_vp]),
     "imatch_knn2_fset": (ctypes.c_int, [c_vp, c_f32p, c_i64, c_vp, c_i32p, c_f32p]),
+    "imatch_knn2_f32_debug_last_path": (ctypes.c_int, [c_vp]),
     "imatch_akaze_last": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i64)]),
     "imatch_knn2_fset_akaze": (ctypes.c_int, [c_vp, ctypes.c_uint64, c_vp, c_i32p, c_f32p]),
     "imatch_akaze_extract": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -547,6 +548,10 @@ class Context:
             self._check(self.lib.imatch_knn2_f32(self._h, _ptr(q, c_f32p), len(q), _ptr(t, c_f32p), len(t), d,
                                                  _ptr(idx, c_i32p), _ptr(dist, c_f32p)))
         return idx, dist
+
+    def knn2_f32_last_path(self):
+        """Test hook: 0 = the last float kNN call ran the exhaustive kernel, 1 = filter + refinement, 2 = filter, then exhaustive."""
+        return int(self.lib.imatch_knn2_f32_debug_last_path(self._h))
 
     def akaze_last(self):
         """(serial, n) of this context's last AKAZE extraction, whose descriptors are still on the device; serial 0: none."""

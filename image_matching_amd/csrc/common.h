@@ -29,6 +29,7 @@ struct imatch_ctx {
     hipEvent_t st_ev[IMATCH_STAGE_COUNT][2];
     unsigned st_seen;      // bit s: stage s has been bracketed at least once since profiling was switched on
     int knn_last_chunks;   // train chunks of the last kNN launch (imatch_knn2_debug_last_chunks)
+    int knnf_last_path;    // the float kNN's last call: 0 exhaustive kernel, 1 filter + refinement, 2 filter tried, then exhaustive (imatch_knn2_f32_debug_last_path)
     // SIFT pyramid arena of the last extraction (kept for reuse by the next frame of the same size)
     struct imatch_sift_state* sift;
     struct imatch_workers* workers;   // host worker pool, created on first use

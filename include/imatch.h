@@ -272,6 +272,12 @@ int imatch_knn2_fset(imatch_ctx* ctx, const float* q, int64_t nq, const imatch_f
  * keypoint; *n its keypoints, may be null); imatch_knn2_fset_akaze matches THAT extraction's descriptors, where they
  * lie, against a resident set: idx/dist [n][2] as imatch_knn2_fset gives them for the downloaded matrix, bit for bit.
  * IMATCH_EINVAL when another extraction has run on the context since (the caller then uploads its host copy). */
+/* Resident sets of 4096 rows and more are answered by a filter on the f16 matrix cores (rows that can be among a query's
+ * two nearest, with a proven error bound) followed by the exact f32 chain on those rows only -- the same bits as the
+ * exhaustive kernel, which remains the path of small sets, of sets with values beyond +-1024 or non-finite ones, of more
+ * than 16384 queries per call and of calls whose candidate lists overflow. Test hook: the path the context's last float
+ * kNN call took (0 exhaustive, 1 filter + refinement, 2 filter tried, then exhaustive). */
+int imatch_knn2_f32_debug_last_path(imatch_ctx* ctx);
 int imatch_akaze_last(imatch_ctx* ctx, uint64_t* serial, int64_t* n);
 int imatch_knn2_fset_akaze(imatch_ctx* ctx, uint64_t serial, const imatch_fset* t, int32_t* idx, float* dist);
 /* Merge step after the all-gather of per-shard top-2 (no reference counterpart: the reference is

@@ -77,6 +77,70 @@ def test_last_akaze_extraction_matched_where_it_lies(ctx):
     fs.free()
 
 
+@pytest.mark.parametrize("nq,nt,d,kind", [(3000, 30000, 64, "unit"), (1, 4096, 64, "unit"), (777, 50001, 64, "unit"),
+                                          (500, 8192, 128, "unit"), (300, 6000, 7, "unit"), (257, 5000, 33, "scaled"),
+                                          (400, 9000, 64, "tiny"), (400, 9000, 64, "sift"), (16384, 4100, 64, "unit")])
+def test_resident_set_filter_path_is_bit_exact(ctx, nq, nt, d, kind):
+    """Resident sets of 4096 rows and more go through the f16 matrix-core filter + exact refinement (kf_filter_kernel /
+    kf_refine_kernel): the answer must be the exhaustive kernel's and the oracle's bit for bit -- unit rows, rows of
+    other scales (norms 1e-3 .. 30), rows of tiny values (f16 subnormals), integer-valued rows up to 255, planted exact
+    duplicates (index order on ties) and clusters of near-duplicates around the second-best distance."""
+    rng = np.random.default_rng(nq + nt + d)
+    q, t = _unit(nq, d, nq + d), _unit(nt, d, nt + 1)
+    if kind == "scaled":
+        t *= rng.uniform(1e-3, 30.0, size=(nt, 1)).astype(np.float32)
+        q *= rng.uniform(1e-3, 30.0, size=(nq, 1)).astype(np.float32)
+    elif kind == "tiny":
+        t *= np.float32(3e-5); q *= np.float32(3e-5)
+    elif kind == "sift":
+        t = np.rint(np.abs(t) * 400).clip(0, 255).astype(np.float32); q = np.rint(np.abs(q) * 400).clip(0, 255).astype(np.float32)
+    k = min(nq, 64)
+    src = rng.choice(nt, k, replace=False)
+    q[:k] = t[src]                                        # exact hits
+    dup = rng.choice(nt, k, replace=False)
+    t[dup] = t[src]                                       # ... that exist twice: ties at distance 0, lower index first
+    q[:k] = t[src]
+    if nq > 200:                                           # clusters of near-duplicates of a query's neighbours
+        for i in range(100, 110):
+            near = rng.choice(nt, 40, replace=False)
+            t[near] = q[i] + (rng.normal(size=(40, d)) * 1e-3 * max(float(np.linalg.norm(q[i])), 1e-6)).astype(np.float32)
+    fs = ctx.fset(t)
+    gi, gd = ctx.knn2_f32(q, fs)
+    assert ctx.knn2_f32_last_path() == 1                  # the filter answered, nobody fell back
+    n_chk = nq if nq * nt <= 1.6e8 else 400
+    pick = np.r_[0:min(n_chk, nq)] if n_chk == nq else np.unique(np.r_[0:128, rng.choice(nq, n_chk, replace=False)])
+    wi, wd = oracle.knn2(q[pick], t)
+    assert np.array_equal(gi[pick], wi) and np.array_equal(gd[pick], wd)
+    if n_chk != nq:                                        # the rest against the exhaustive kernel on the GPU
+        ei, ed = ctx.knn2_f32(q, t)
+        assert ctx.knn2_f32_last_path() == 0
+        assert np.array_equal(gi, ei) and np.array_equal(gd, ed)
+    fs.free()
+
+
+def test_filter_path_hands_over_when_it_cannot_answer(ctx):
+    """Values beyond the f16 path's range (either side), non-finite values and a candidate list that overflows (a set of
+    identical rows: every row is a candidate) all end in the exhaustive kernel's answer."""
+    t = _unit(5000, 64, 1)
+    q = _unit(50, 64, 2)
+    t_big = t.copy(); t_big[17, 3] = 5000.0
+    for tt, qq in ((t_big, q), (t, q * np.float32(3000.0))):
+        fs = ctx.fset(tt)
+        gi, gd = ctx.knn2_f32(qq, fs)
+        assert ctx.knn2_f32_last_path() in (0, 2)         # the set did not qualify (0) or the query flagged itself (2)
+        wi, wd = oracle.knn2(qq, tt)
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+        fs.free()
+    same = np.repeat(_unit(1, 64, 3), 6000, axis=0)           # 6000 identical rows: more candidates than a list holds
+    fs = ctx.fset(same)
+    gi, gd = ctx.knn2_f32(q, fs)
+    assert ctx.knn2_f32_last_path() == 2                  # lists overflowed: the exhaustive kernel answered
+    assert (gi[:, 0] == 0).all() and (gi[:, 1] == 1).all()
+    wi, wd = oracle.knn2(q, same)
+    assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+    fs.free()
+
+
 def test_empty_and_ties(ctx):
     q = _unit(10, 64, 1)
     gi, gd = ctx.knn2_f32(q, np.zeros((0, 64), np.float32))
