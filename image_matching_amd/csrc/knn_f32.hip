@@ -125,7 +125,9 @@ knn2_f32_finish_kernel(const kf_top2* __restrict__ partial, int n_chunks, int64_
 // below 2^-14 an absolute 2^-25), the products are summed in f32, so |a - s| <= e_q + e_t with
 //     e_row = |row|^2 * 2^-9 + |row| * 2^-20
 // (twice the first-order bound 2^-10 |q||t| + 2^-25 sqrt(d) (|q| + |t|), which leaves room for the f32 summation errors on
-// both sides). Every lane keeps the two smallest UPPER bounds U = a + e it has seen for its query: two rows lie at or below
+// both sides; the second term is the f16 SUBNORMAL range, which conversion and MFMA both keep on gfx950 -- rows whose every
+// component is subnormal in f16 go through the filter exactly, tests/test_knn_f32_gpu.py "tiny": were they flushed, every
+// row would be a candidate and the lists would overflow). Every lane keeps the two smallest UPPER bounds U = a + e it has seen for its query: two rows lie at or below
 // U2, so the query's true second-best does too, and a row can only belong to the true top-2 if its LOWER bound a - e is
 // <= U2 (the factor 1 + 2^-18 covers rows whose s is larger but whose sqrtf rounds to the same float -- the order is on the
 // distance, ties to the lower index). Such rows are appended to the query's candidate list; U2 only falls while the map is
