@@ -123,6 +123,65 @@ homography_score_kernel(const double* __restrict__ pts_all, const float* __restr
     atomicMax(best + b, key);
 }
 
+// The same scores for a single problem (or a few), where a thread per hypothesis leaves the chip idle: a frame's 4096
+// hypotheses are 64 waves of one long serial loop each (25-35 us for 100 correspondences, 130 us for 1500). Here a workgroup
+// takes 16 hypotheses: sixteen lanes build them (the closed form is a long chain of f64 divisions -- a wave per hypothesis
+// building its own was slower than the thread-per-hypothesis kernel), then each wave scores four of them with its 64 lanes
+// on 64 correspondences at a time, and the terms are added in index order, one v_readlane + one v_add_f32 each: the sum
+// every thread of homography_score_kernel forms, bit for bit (a term that is not > 0 is added as + 0, which leaves a
+// non-negative sum as it is). A batch keeps the thread-per-hypothesis kernel: its million hypotheses fill the chip as they are.
+#define HOMO_WG_HYP 16
+__global__ void __launch_bounds__(256)
+homography_score_wg_kernel(const double* __restrict__ pts_all, const float* __restrict__ fpts_all, HomoSeg hs,
+                           unsigned long long* __restrict__ best) {
+    __shared__ float Hs[HOMO_WG_HYP][9];
+    __shared__ int ok[HOMO_WG_HYP];
+    const int b = blockIdx.y;
+    const int n = hs.seg.off[b + 1] - hs.seg.off[b];
+    if (n < 4) return;
+    const double* pts = pts_all + 4 * (size_t)hs.seg.off[b];
+    const float* fpts = fpts_all + 4 * (size_t)hs.seg.off[b];
+    const float inv_tau2 = hs.inv_tau2[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t h0 = blockIdx.x * HOMO_WG_HYP;
+    if (threadIdx.x < HOMO_WG_HYP) {
+        const uint32_t h = h0 + threadIdx.x;
+        double H[9];
+        const bool good = h < HOMO_HYPOTHESES && hypothesis(pts, n, hs.seeds[b], h, H);
+        ok[threadIdx.x] = good;
+        if (good)
+            for (int k = 0; k < 9; ++k) Hs[threadIdx.x][k] = (float)H[k];
+    }
+    __syncthreads();
+    const float *sx = fpts, *sy = fpts + n, *dx = fpts + 2 * n, *dy = fpts + 3 * n;
+    for (int j = 0; j < HOMO_WG_HYP / 4; ++j) {
+        const int hl = wave * (HOMO_WG_HYP / 4) + j;     // wave-uniform
+        if (!ok[hl]) continue;
+        float Hf[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Hf[k] = Hs[hl][k];
+        float score = 0.f;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            float t = 0.f;
+            if (i < n) {
+                const float w = Hf[6] * sx[i] + Hf[7] * sy[i] + Hf[8];
+                const float u = (Hf[0] * sx[i] + Hf[1] * sy[i] + Hf[2]) / w;
+                const float v = (Hf[3] * sx[i] + Hf[4] * sy[i] + Hf[5]) / w;
+                const float ex = u - dx[i], ey = v - dy[i];
+                t = 1.f - (ex * ex + ey * ey) * inv_tau2;
+                if (!(t > 0.f)) t = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 64; ++k) score += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), k));
+        }
+        if (lane == 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (0xFFFFFFFFu - (h0 + (uint32_t)hl));
+            atomicMax(best + b, key);
+        }
+    }
+}
+
 static void hartley(const float* p, int n, double T[3]) {
     double cx = 0, cy = 0;
     for (int i = 0; i < n; ++i) { cx += p[2 * i]; cy += p[2 * i + 1]; }
@@ -246,11 +305,20 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
     hs.inv_tau2 = (const float*)(dev + dbytes + fbytes + sbytes);
     HIP_TRY(ctx, hipMemcpyAsync(dev, ctx->hs, up_bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_best, 0, kbytes, ctx->stream));
-    // one problem: single-wave workgroups, or its 4096 hypotheses sit on 16 of the 256 CUs
-    const int wg = nseg >= 8 ? 256 : 64;
+    // one problem (or a few): sixteen hypotheses per workgroup, scored by its waves; a batch: a thread per hypothesis (same
+    // scores bit for bit)
+    static const int wave_env = getenv("IMATCH_HOMO_WAVE") ? atoi(getenv("IMATCH_HOMO_WAVE")) : 1;   // 0: A/B runs
     (void)imatch_stage_begin(ctx, IMATCH_STAGE_HOMOGRAPHY, ctx->stream);
-    hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / wg, nseg), dim3(wg), 0, ctx->stream,
-                       (const double*)dev, (const float*)(dev + dbytes), hs, d_best);
+    // (with a hundred correspondences the hypotheses' construction, a serial f64 chain, is most of either kernel and the
+    // thread-per-hypothesis form is the shorter one: 93 against 121 us per call; with 1500 it is 354 against 288)
+    int n_max = 0;
+    for (int b = 0; b < nseg; ++b) n_max = std::max(n_max, seg.off[b + 1] - seg.off[b]);
+    if (nseg < 8 && wave_env && n_max >= 512)
+        hipLaunchKernelGGL(homography_score_wg_kernel, dim3(HOMO_HYPOTHESES / HOMO_WG_HYP, nseg), dim3(256), 0, ctx->stream,
+                           (const double*)dev, (const float*)(dev + dbytes), hs, d_best);
+    else
+        hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / (nseg >= 8 ? 256 : 64), nseg), dim3(nseg >= 8 ? 256 : 64), 0,
+                           ctx->stream, (const double*)dev, (const float*)(dev + dbytes), hs, d_best);
     HIP_TRY(ctx, hipGetLastError());
     (void)imatch_stage_end(ctx, IMATCH_STAGE_HOMOGRAPHY, ctx->stream);
     unsigned long long* h_key = (unsigned long long*)((char*)ctx->hs + up_bytes);  // pinned: no staging copy

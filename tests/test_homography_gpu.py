@@ -60,3 +60,19 @@ def test_homography_is_reproducible_and_seeded(ctx):
     c, _ = ctx.homography(src, dst, 0.1, seed=8)
     assert np.array_equal(a, b)
     assert np.abs(_proj(a) - _proj(c)).max() < 0.5
+
+
+def test_large_problem_kernel_scores_like_the_batch_kernel(ctx):
+    """A single problem of 512 correspondences and more is scored by homography_score_wg_kernel (sixteen hypotheses per
+    workgroup, terms added in index order), a batch of eight and more by the thread-per-hypothesis kernel: the same
+    winner, so the same H and mask bit for bit, and the oracle's within 1e-3 px."""
+    src, dst, _ = _case(21, 1500, 0.35)
+    H1, m1 = ctx.homography(src, dst, 0.1, seed=5)
+    small = [_case(30 + k, 40, 0.2)[:2] for k in range(7)]
+    srcs = np.concatenate([src] + [s for s, _ in small])
+    dsts = np.concatenate([dst] + [d for _, d in small])
+    offs = np.cumsum([0, 1500] + [40] * 7)
+    Hb, mb, found = ctx.homography_batch(srcs, dsts, offs, 0.1, seeds=np.array([5] + list(range(100, 107))))
+    assert found[0] and np.array_equal(np.asarray(Hb[0]), H1) and np.array_equal(np.asarray(mb[:1500]).reshape(-1), m1.reshape(-1))
+    Ho, mo = oracle.homography(src, dst, 0.1, seed=5)
+    assert np.abs(_proj(H1) - _proj(Ho)).max() <= 1e-3 and np.array_equal(m1, mo)
