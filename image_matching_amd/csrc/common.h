@@ -29,6 +29,11 @@ struct imatch_ctx {
     hipEvent_t st_ev[IMATCH_STAGE_COUNT][2];
     unsigned st_seen;      // bit s: stage s has been bracketed at least once since profiling was switched on
     int knn_last_chunks;   // train chunks of the last kNN launch (imatch_knn2_debug_last_chunks)
+    // bound words of the int8 kNN (three per query), a pool block of the context: all KNN_INF between launches when
+    // knn_gthr_armed (the merge kernel of a launch puts back what the launch used)
+    int* knn_gthr;
+    size_t knn_gthr_words;
+    int knn_gthr_armed;
     int knnf_last_path;    // the float kNN's last call: 0 exhaustive kernel, 1 filter + refinement, 2 filter tried, then exhaustive (imatch_knn2_f32_debug_last_path)
     // SIFT pyramid arena of the last extraction (kept for reuse by the next frame of the same size)
     struct imatch_sift_state* sift;

@@ -209,39 +209,85 @@ static bool solve8(double A[8][9]) {
     return true;
 }
 
-// Tukey-weighted least squares rounds, then Gauss-Newton on the forward transfer error
-static bool refit(const double* P, int n, double tau2, double h8[8]) {
+// Tukey-weighted least squares rounds, then Gauss-Newton on the forward transfer error. The normal equations
+//     N[a][b] = sum_i w_i r1_i[a] r1_i[b] + w_i r2_i[a] r2_i[b],   r1 = (p0 p1 p2 0 0 0 p3 p4 p5),  r2 = (0 0 0 q0 q1 q2 q3 q4 q5)
+// are summed point after point in index order, every term as (w r[a]) r[b] and r1's before r2's, exactly as
+// oracle/homography_oracle.c does it -- but only where the rows are not structurally zero (a term w r[a] 0 adds +-0 and
+// changes nothing), four columns per vector operation, and with the per-point part (projection, error, weight: four
+// divisions) in a loop of its own that the compiler vectorises over points. Same IEEE operations on the same operands in the
+// same order: the result is the scalar loop's bit for bit (a 1 500-point refit 0.49 -> 0.18 ms, a 115-point one 37 -> 14 us
+// on the development host; an AVX2 clone is picked at load time, no fused multiply-add in either).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IMATCH_HOST_CLONES
+#else
+#define IMATCH_HOST_CLONES __attribute__((target_clones("avx2", "default")))
+#endif
+typedef double v4d __attribute__((vector_size(32)));
+#define V4D_ALL(s) ((v4d){(s), (s), (s), (s)})
+
+// ws: [6][n] doubles of scratch
+IMATCH_HOST_CLONES
+static bool refit(const double* __restrict__ P, int n, double tau2, double h8[8], double* __restrict__ ws) {
     const double *sx = P, *sy = P + n, *dx = P + 2 * n, *dy = P + 3 * n;
-    std::vector<double> w((size_t)n, 0.0);
+    double *w = ws, *a_ww = ws + n, *a_pu = ws + 2 * (size_t)n, *a_pv = ws + 3 * (size_t)n, *a_ex = ws + 4 * (size_t)n,
+           *a_ey = ws + 5 * (size_t)n;
+    for (int i = 0; i < n; ++i) w[i] = 0.0;
     for (int it = 0; it < HOMO_IRLS + HOMO_GN; ++it) {
-        double N[8][9];
-        memset(N, 0, sizeof(N));
-        int cnt = 0;
-        for (int i = 0; i < n; ++i) {
-            const double x = sx[i], y = sy[i], u = dx[i], v = dy[i];
-            const double ww = h8[6] * x + h8[7] * y + 1.0;
-            const double pu = (h8[0] * x + h8[1] * y + h8[2]) / ww, pv = (h8[3] * x + h8[4] * y + h8[5]) / ww;
-            const double ex = u - pu, ey = v - pv, e2 = ex * ex + ey * ey;
-            if (it <= HOMO_IRLS) {  // frozen during the remaining Gauss-Newton steps
-                const double t = 1.0 - e2 / tau2;
-                w[i] = t > 0 ? t * t : 0.0;
-            }
-            if (w[i] <= 0) continue;
-            ++cnt;
-            double r1[9], r2[9];
-            if (it < HOMO_IRLS) {
-                r1[0] = x; r1[1] = y; r1[2] = 1; r1[3] = 0; r1[4] = 0; r1[5] = 0; r1[6] = -x * u; r1[7] = -y * u; r1[8] = u;
-                r2[0] = 0; r2[1] = 0; r2[2] = 0; r2[3] = x; r2[4] = y; r2[5] = 1; r2[6] = -x * v; r2[7] = -y * v; r2[8] = v;
-            } else {
-                const double iw = 1.0 / ww;
-                r1[0] = x * iw; r1[1] = y * iw; r1[2] = iw; r1[3] = 0; r1[4] = 0; r1[5] = 0; r1[6] = -x * pu * iw; r1[7] = -y * pu * iw; r1[8] = ex;
-                r2[0] = 0; r2[1] = 0; r2[2] = 0; r2[3] = x * iw; r2[4] = y * iw; r2[5] = iw; r2[6] = -x * pv * iw; r2[7] = -y * pv * iw; r2[8] = ey;
-            }
-            for (int a = 0; a < 8; ++a) {
-                if (r1[a] != 0) for (int b = 0; b < 9; ++b) N[a][b] += w[i] * r1[a] * r1[b];
-                if (r2[a] != 0) for (int b = 0; b < 9; ++b) N[a][b] += w[i] * r2[a] * r2[b];
+        {
+            const double h0 = h8[0], h1 = h8[1], h2 = h8[2], h3 = h8[3], h4 = h8[4], h5 = h8[5], h6 = h8[6], h7 = h8[7];
+            const bool reweigh = it <= HOMO_IRLS;  // frozen during the remaining Gauss-Newton steps
+            for (int i = 0; i < n; ++i) {
+                const double x = sx[i], y = sy[i];
+                const double ww = h6 * x + h7 * y + 1.0;
+                const double pu = (h0 * x + h1 * y + h2) / ww, pv = (h3 * x + h4 * y + h5) / ww;
+                const double ex = dx[i] - pu, ey = dy[i] - pv, e2 = ex * ex + ey * ey;
+                a_ww[i] = ww; a_pu[i] = pu; a_pv[i] = pv; a_ex[i] = ex; a_ey[i] = ey;
+                if (reweigh) {
+                    const double t = 1.0 - e2 / tau2;
+                    w[i] = t > 0 ? t * t : 0.0;
+                }
             }
         }
+        // rows 0-2 on columns {0,1,2} (Al) and {6,7,8} (Ah), rows 3-5 on {3,4,5} (Bl) and {6,7,8} (Bh), rows 6-7 on all nine
+        const v4d z = V4D_ALL(0.0);
+        v4d Al[3] = {z, z, z}, Ah[3] = {z, z, z}, Bl[3] = {z, z, z}, Bh[3] = {z, z, z}, D0[2] = {z, z}, D3[2] = {z, z}, D6[2] = {z, z};
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            const double wi = w[i];
+            if (!(wi > 0)) continue;
+            ++cnt;
+            const double x = sx[i], y = sy[i], u = dx[i], v = dy[i];
+            double p[6], q[6];
+            if (it < HOMO_IRLS) {
+                p[0] = x; p[1] = y; p[2] = 1; p[3] = -x * u; p[4] = -y * u; p[5] = u;
+                q[0] = x; q[1] = y; q[2] = 1; q[3] = -x * v; q[4] = -y * v; q[5] = v;
+            } else {
+                const double iw = 1.0 / a_ww[i], pu = a_pu[i], pv = a_pv[i];
+                p[0] = x * iw; p[1] = y * iw; p[2] = iw; p[3] = -x * pu * iw; p[4] = -y * pu * iw; p[5] = a_ex[i];
+                q[0] = x * iw; q[1] = y * iw; q[2] = iw; q[3] = -x * pv * iw; q[4] = -y * pv * iw; q[5] = a_ey[i];
+            }
+            const v4d pl = {p[0], p[1], p[2], 0.0}, ph = {p[3], p[4], p[5], 0.0};
+            const v4d ql = {q[0], q[1], q[2], 0.0}, qh = {q[3], q[4], q[5], 0.0};
+            for (int a = 0; a < 3; ++a) {
+                const v4d wa = V4D_ALL(wi * p[a]), wb = V4D_ALL(wi * q[a]);
+                Al[a] += wa * pl; Ah[a] += wa * ph;
+                Bl[a] += wb * ql; Bh[a] += wb * qh;
+            }
+            for (int a = 0; a < 2; ++a) {
+                const v4d wa = V4D_ALL(wi * p[3 + a]), wb = V4D_ALL(wi * q[3 + a]);
+                D0[a] += wa * pl; D3[a] += wb * ql;
+                D6[a] += wa * ph; D6[a] += wb * qh;   // r1's term first
+            }
+        }
+        double N[8][9];
+        memset(N, 0, sizeof(N));
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                N[a][b] = Al[a][b]; N[a][6 + b] = Ah[a][b];
+                N[3 + a][3 + b] = Bl[a][b]; N[3 + a][6 + b] = Bh[a][b];
+            }
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 3; ++b) { N[6 + a][b] = D0[a][b]; N[6 + a][3 + b] = D3[a][b]; N[6 + a][6 + b] = D6[a][b]; }
         if (cnt < 4 || !solve8(N)) return it > 0;
         if (it < HOMO_IRLS) for (int k = 0; k < 8; ++k) h8[k] = N[k][8];
         else for (int k = 0; k < 8; ++k) h8[k] += N[k][8];
@@ -303,8 +349,11 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
     unsigned long long* d_best = (unsigned long long*)(dev + up_bytes);
     hs.seeds = (const unsigned long long*)(dev + dbytes + fbytes);
     hs.inv_tau2 = (const float*)(dev + dbytes + fbytes + sbytes);
-    HIP_TRY(ctx, hipMemcpyAsync(dev, ctx->hs, up_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(d_best, 0, kbytes, ctx->stream));
+    // the result keys start at zero: they travel up as zeros behind the points (one operation instead of copy + clear) and
+    // come back into the same pinned words
+    unsigned long long* h_key = (unsigned long long*)((char*)ctx->hs + up_bytes);
+    memset(h_key, 0, kbytes);
+    HIP_TRY(ctx, hipMemcpyAsync(dev, ctx->hs, up_bytes + kbytes, hipMemcpyHostToDevice, ctx->stream));
     // one problem (or a few): sixteen hypotheses per workgroup, scored by its waves; a batch: a thread per hypothesis (same
     // scores bit for bit)
     static const int wave_env = getenv("IMATCH_HOMO_WAVE") ? atoi(getenv("IMATCH_HOMO_WAVE")) : 1;   // 0: A/B runs
@@ -321,7 +370,6 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
                            ctx->stream, (const double*)dev, (const float*)(dev + dbytes), hs, d_best);
     HIP_TRY(ctx, hipGetLastError());
     (void)imatch_stage_end(ctx, IMATCH_STAGE_HOMOGRAPHY, ctx->stream);
-    unsigned long long* h_key = (unsigned long long*)((char*)ctx->hs + up_bytes);  // pinned: no staging copy
     HIP_TRY(ctx, hipMemcpyAsync(h_key, d_best, kbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     auto finish = [&](int b) {
@@ -338,7 +386,8 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
         if (!hypothesis(P, n, seeds[b], h, Hb) || fabs(Hb[8]) <= 1e-9) return;
         double h8[8];
         for (int k = 0; k < 8; ++k) h8[k] = Hb[k] / Hb[8];
-        if (!refit(P, n, tau[b] * tau[b], h8)) return;
+        std::vector<double> scratch(6 * (size_t)n);
+        if (!refit(P, n, tau[b] * tau[b], h8, scratch.data())) return;
         const double Hn[9] = {h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7], 1.0};
         const double TS[9] = {ts[0], 0, -ts[0] * ts[1], 0, ts[0], -ts[0] * ts[2], 0, 0, 1};
         const double TDi[9] = {1.0 / td[0], 0, td[1], 0, 1.0 / td[0], td[2], 0, 0, 1};

@@ -467,8 +467,13 @@ __device__ inline void top2_insert(int& s1, int& j1, int& s2, int& j2, int s, in
 // 256 threads = 16 queries x 16 list slices; the slices are combined through LDS.
 __global__ void __launch_bounds__(256)
 knn2_finish_kernel(const int2* __restrict__ pb, const int2* __restrict__ pi, int nLists, int64_t Qpad,
-                   const int* __restrict__ qnorm, int64_t nq, int64_t nt, int idx_offset, int4* __restrict__ out) {
+                   const int* __restrict__ qnorm, int64_t nq, int64_t nt, int idx_offset, int4* __restrict__ out,
+                   int* __restrict__ rearm, int64_t n_rearm) {
     __shared__ int4 part[16][16];
+    // the launch before this one is done with its bound words: they go back to "no bound" for the context's next launch
+    // (the context's own block, see knn2_run: no clear in front of the next kNN)
+    if (rearm)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rearm; i += (int64_t)gridDim.x * 256) rearm[i] = 0x7f7f7f7f;
     const int ql = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int64_t q = (int64_t)blockIdx.x * 16 + ql;
     int s1 = INT_MAX, s2 = INT_MAX, j1 = INT_MAX, j2 = INT_MAX;
@@ -844,7 +849,8 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     const int64_t nLists = nChunks;   // the kernel merges its four row quarters itself: one list per chunk
     ctx->knn_last_chunks = nChunks;
     const size_t pbytes = (size_t)nLists * Qpad * 8;
-    if (!ws) {
+    const bool own_ws = !ws;
+    if (own_ws) {
         int rc = imatch_ws_reserve(ctx, 2 * pbytes + gbytes);
         if (rc) return rc;
         ws = ctx->ws;
@@ -852,7 +858,29 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     int2* pb = (int2*)ws;
     int2* pi = (int2*)((char*)ws + pbytes);
     int* gthr = (int*)((char*)ws + 2 * pbytes);
-    HIP_TRY(ctx, hipMemsetAsync(gthr, 0x7f, gbytes, ctx->stream));  // KNN_INF in every word
+    // The bound words start at KNN_INF. With the context's workspace they live in a block of the context's own that is
+    // cleared when it is made or grown and put back in order by the merge kernel of every launch (4 us of clear plus a
+    // launch gap in front of a frame's 0.1 ms kNN); a launch that failed half-way leaves the block marked and the next
+    // one clears it. The caller-supplied scratch block is cleared per call.
+    int* rearm = nullptr;
+    if (own_ws) {
+        const size_t words = gbytes / 4;
+        if (ctx->knn_gthr_words < words) {
+            imatch_pool_free(ctx, ctx->knn_gthr);
+            ctx->knn_gthr_words = 0;
+            const size_t cap_words = std::max(words, (size_t)3 * 16384);
+            ctx->knn_gthr = (int*)imatch_pool_alloc(ctx, cap_words * 4);
+            if (!ctx->knn_gthr) return imatch_set_err(ctx, IMATCH_ENOMEM, "kNN bound words");
+            ctx->knn_gthr_words = cap_words;
+            ctx->knn_gthr_armed = 0;
+        }
+        gthr = ctx->knn_gthr;
+        if (!ctx->knn_gthr_armed) HIP_TRY(ctx, hipMemsetAsync(gthr, 0x7f, ctx->knn_gthr_words * 4, ctx->stream));
+        ctx->knn_gthr_armed = 0;
+        rearm = gthr;
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(gthr, 0x7f, gbytes, ctx->stream));  // KNN_INF in every word
+    }
     { const int rcs = imatch_stage_begin(ctx, IMATCH_STAGE_KNN, ctx->stream); if (rcs) return rcs; }
     {
         const unsigned grid = (unsigned)(nQt * nChunks);
@@ -875,8 +903,9 @@ static int knn2_run(imatch_ctx* ctx, const imatch_features* q, const imatch_feat
     { const int rcs = imatch_stage_end(ctx, IMATCH_STAGE_KNN, ctx->stream); if (rcs) return rcs; }
     { const int rcs = imatch_stage_begin(ctx, IMATCH_STAGE_KNN_MERGE, ctx->stream); if (rcs) return rcs; }
     hipLaunchKernelGGL(knn2_finish_kernel, dim3((unsigned)((q->n + 15) / 16)), dim3(256), 0, ctx->stream, pb, pi,
-                       (int)nLists, Qpad, q->norm, q->n, t->n, idx_offset, (int4*)out4_dev);
+                       (int)nLists, Qpad, q->norm, q->n, t->n, idx_offset, (int4*)out4_dev, rearm, (int64_t)(gbytes / 4));
     HIP_TRY(ctx, hipGetLastError());
+    if (own_ws) ctx->knn_gthr_armed = 1;
     { const int rcs = imatch_stage_end(ctx, IMATCH_STAGE_KNN_MERGE, ctx->stream); if (rcs) return rcs; }
     return IMATCH_OK;
 }

@@ -88,13 +88,15 @@ struct imatch_sift_state {
     hipEvent_t ev_sorted;
     // the one-workgroup-per-octave form of the small-octave kernel once timed out on this context: it is not used again
     bool no_tail_split;
-    hipEvent_t ev_counts;   // recorded behind the count / record copies of a single frame (the descriptor launches follow it)
+    hipEvent_t ev_counts;   // recorded behind the count / record copies of a single frame (on the copy stream)
+    hipEvent_t ev_image;    // ... and behind the copy of the equalised image that follows them there
 };
 
 void imatch_sift_state_free(imatch_ctx* ctx) {
     if (!ctx || !ctx->sift) return;
     if (ctx->sift->arena) (void)hipFree(ctx->sift->arena);
     if (ctx->sift->ev_counts) (void)hipEventDestroy(ctx->sift->ev_counts);
+    if (ctx->sift->ev_image) (void)hipEventDestroy(ctx->sift->ev_image);
     if (ctx->sift->copy) {
         (void)hipStreamSynchronize(ctx->sift->copy);
         (void)hipEventDestroy(ctx->sift->ev_sorted);
@@ -2032,30 +2034,45 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             ~CopyGuard() { (void)wait(); }
         } rec_copy{nullptr, false};
         const bool copy_aside = dev_sort && (size_t)batch * kp_hint * sizeof(KpRec) >= ((size_t)1 << 20);
-        HIP_TRY(ctx, hipMemcpy2DAsync(h_cnt, 32, d_cnt, zs, 32, (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
-        if (copy_aside) {
-            if (!S->copy) {
-                HIP_TRY(ctx, hipStreamCreateWithFlags(&S->copy, hipStreamNonBlocking));
-                HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_sorted, hipEventDisableTiming));
-            }
+        // a single frame sorted on the device: both copies (and the copy of the equalised image the set keeps) leave on
+        // the copy stream, the descriptor launches follow the sort on the main stream at once -- the two copies used to sit
+        // between the sort and the descriptor kernel, 30 us of a frame in which the GPU did nothing else
+        const bool spec_frame = spec_env && batch == 1 && dev_sort && S->kp_hint > 0 && !copy_aside;
+        if ((copy_aside || spec_frame) && !S->copy) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&S->copy, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_sorted, hipEventDisableTiming));
+        }
+        if (copy_aside || spec_frame) {
             HIP_TRY(ctx, hipEventRecord(S->ev_sorted, ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(S->copy, S->ev_sorted, 0));
             rec_copy.s = S->copy;
             rec_copy.pending = true;
+        }
+        HIP_TRY(ctx, hipMemcpy2DAsync(h_cnt, 32, d_cnt, zs, 32, (size_t)batch, hipMemcpyDeviceToHost, spec_frame ? S->copy : ctx->stream));
+        if (copy_aside || spec_frame) {
             HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), d_sorted, zs, (size_t)kp_hint * sizeof(KpRec),
                                           (size_t)batch, hipMemcpyDeviceToHost, S->copy));
         } else {
             HIP_TRY(ctx, hipMemcpy2DAsync(h_kp, (size_t)kp_hint * sizeof(KpRec), dev_sort ? d_sorted : d_kp, zs,
                                           (size_t)kp_hint * sizeof(KpRec), (size_t)batch, hipMemcpyDeviceToHost, ctx->stream));
         }
-        // the host waits for the copies only: the descriptor launches queued behind them run while it sorts out the counts
+        // the host waits for the copies only: the descriptor launches run while it sorts out the counts
         bool wait_on_event = false;
-        if (spec_env && batch == 1 && dev_sort && S->kp_hint > 0 && !copy_aside) {
+        if (spec_frame) {
             if (!S->ev_counts) HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_counts, hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventRecord(S->ev_counts, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(S->ev_counts, S->copy));
             wait_on_event = true;
             rc = imatch_features_alloc(ctx, n_sort, &spec.f);
             if (rc) return rc;
+            if (P->clahe) {   // the set's copy of the equalised image: on the copy stream too; the main stream (so every later
+                              // reader of the copy, and the next frame's CLAHE) waits for it behind the descriptor launches
+                spec.f->image = (uint8_t*)imatch_pool_alloc(ctx, (size_t)h * w);
+                if (!spec.f->image) return imatch_set_err(ctx, IMATCH_ENOMEM, "image copy");
+                spec.f->img_h = h; spec.f->img_w = w;
+                if (!S->ev_image) HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_image, hipEventDisableTiming));
+                HIP_TRY(ctx, hipMemcpyAsync(spec.f->image, d_clahe, (size_t)h * w, hipMemcpyDeviceToDevice, S->copy));
+                HIP_TRY(ctx, hipEventRecord(S->ev_image, S->copy));
+            }
             SegTab seg1;
             memset(&seg1, 0, sizeof(seg1));
             seg1.n = 1;
@@ -2067,6 +2084,10 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             (void)imatch_stage_end(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
             rc = imatch_features_pad_counted_dev(ctx, spec.f, d_cnt + 3);
             if (rc) return rc;
+            // everything the copy stream reads (counters, records, the equalised image) is the arena's: whatever the main
+            // stream runs next comes after it
+            if (P->clahe) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, S->ev_image, 0));
+            else HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, S->ev_counts, 0));
         }
         const bool timing = getenv("IMATCH_TIMING") != nullptr;
         const double t_a = now_ms();
@@ -2207,7 +2228,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
                     t_b - t_a, t_c - t_b, t_d - t_c);
         if (offsets)
             for (int b = 0; b <= batch; ++b) offsets[b] = seg.off[b];
-        if (P->clahe && batch == 1) {
+        if (P->clahe && batch == 1 && !f->image) {   // (the set queued ahead of the counts has its copy already)
             f->image = (uint8_t*)imatch_pool_alloc(ctx, (size_t)h * w);
             if (!f->image) {
                 imatch_features_free(f);

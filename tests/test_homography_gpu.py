@@ -76,3 +76,20 @@ def test_large_problem_kernel_scores_like_the_batch_kernel(ctx):
     assert found[0] and np.array_equal(np.asarray(Hb[0]), H1) and np.array_equal(np.asarray(mb[:1500]).reshape(-1), m1.reshape(-1))
     Ho, mo = oracle.homography(src, dst, 0.1, seed=5)
     assert np.abs(_proj(H1) - _proj(Ho)).max() <= 1e-3 and np.array_equal(m1, mo)
+
+
+@pytest.mark.parametrize("seed,n", [(41, 5), (42, 33), (43, 115), (44, 700), (45, 1500)])
+def test_refit_is_the_oracles_bit_for_bit(ctx, seed, n):
+    """The winner's refit runs vectorised on the host (structural zeros of the normal equations skipped, four columns per
+    operation, an AVX2 clone where the CPU has it) and must still be the oracle's scalar loop to the last bit: H equal as
+    float64 words. Coordinates that are exactly 0 take the branch the scalar loop skips on data."""
+    src, dst, _ = _case(seed, n, 0.3)
+    src[::5, 0] = 0.0
+    src[1::7, 1] = 0.0
+    dst[2::9, 0] = 0.0
+    H, mask = ctx.homography(src, dst, 0.1, seed=seed)
+    Ho, mo = oracle.homography(src, dst, 0.1, seed=seed)
+    assert (H is None) == (Ho is None)
+    if H is not None:
+        assert np.array_equal(H, Ho), np.abs(H - Ho).max()
+        assert np.array_equal(mask, mo)
