@@ -412,6 +412,11 @@ def main():
             return mt.match_replicated(f, nq)
         return mt.match_dp(f, nq, cap)
 
+    # a frame alone on one GPU against the real map: the per-frame tail is one library call (IMATCH_BENCH_ONE_CALL=0: the
+    # separate calls, for A/B runs)
+    one_call = (world == 1 and workload == "c1" and n_map == n_real and n_streams == 1
+                and os.environ.get("IMATCH_BENCH_ONE_CALL", "1") != "0")
+
     def step(i, record=False, lane=0):
         cx, mt = ctxs[lane], matchers[lane]
         fr = frames_d[(i * n_streams + lane) % len(frames_d)]
@@ -420,13 +425,18 @@ def main():
         pyr_ms = cx.sift_pyramid_ms() if record else 0.0
         if nq > q_cap:
             raise RuntimeError('frame has %d keypoints, exchange buffers hold %d' % (nq, q_cap))
-        out4 = match(mt, f, nq, q_cap)
-        gq, gt, gd = cx.ratio_dev(out4.data_ptr(), nq, ratio)
-        knn_ms = cx.knn2_kernel_ms() if record else 0.0
-        H = None
-        if len(gq) > 10:                                   # position_finder.py:316
-            kp = f.download(descriptors=False)[0]
-            H, _ = cx.homography(kp[gq, :2], xy_of(gt), 0.1, seed=i)
+        if one_call:
+            # the whole tail in one call of the library (imatch_match_localize): same results as the calls below
+            gq, gt, gd, H, _ = cx.match_localize(f, f_local, ratio, 10, 0.1, seed=i)
+            knn_ms = cx.knn2_kernel_ms() if record else 0.0
+        else:
+            out4 = match(mt, f, nq, q_cap)
+            gq, gt, gd = cx.ratio_dev(out4.data_ptr(), nq, ratio)
+            knn_ms = cx.knn2_kernel_ms() if record else 0.0
+            H = None
+            if len(gq) > 10:                                   # position_finder.py:316
+                kp = f.download(descriptors=False)[0]
+                H, _ = cx.homography(kp[gq, :2], xy_of(gt), 0.1, seed=i)
         f.free()
         if record:
             with stats_lock:
@@ -828,6 +838,8 @@ def main():
         if single_ms is not None:
             out["single_frame"] = {"ms_per_frame": single_ms, "frames_per_s": 1e3 / single_ms,
                                    "ms_per_frame_with_stage_events": single_prof_ms,
+                                   "calls": ("imatch_sift_extract_dev + imatch_match_localize" if one_call else
+                                             "imatch_sift_extract_dev + imatch_knn2_dev + imatch_ratio_dev + imatch_homography"),
                                    "note": "one frame at a time through the single-frame entry points, measured after "
                                            "the timed region (median of five blocks of 30 frames, the library's stage-event brackets off; with them "
                                            "on: ms_per_frame_with_stage_events); not part of value"}

@@ -122,6 +122,10 @@ SIGNATURES = {
     "imatch_sift_debug_layer_rows": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p]),
     "imatch_homography": (ctypes.c_int, [c_vp, c_f32p, c_f32p, ctypes.c_int, ctypes.c_double, ctypes.c_uint64,
                                          ctypes.POINTER(ctypes.c_double), c_u8p, ctypes.POINTER(ctypes.c_int)]),
+    "imatch_match_localize": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_uint64,
+                                             c_i32p, c_i32p, c_f32p, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double),
+                                             c_u8p, ctypes.POINTER(ctypes.c_int)]),
+    "imatch_match_localize_debug_mismatches": (ctypes.c_int, [c_vp]),
     "imatch_knn2": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32p, c_f32p]),
     "imatch_knn2_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
     "imatch_knn2_noalloc_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
@@ -730,6 +734,33 @@ class Context:
                                                   _ptr(gt, c_i32p), _ptr(gd, c_f32p), ctypes.byref(n)))
         g = n.value
         return gq[:g].copy(), gt[:g].copy(), gd[:g].copy()
+
+    def match_localize(self, q, t, ratio=0.7, min_good=10, thr=0.1, seed=0):
+        """One frame's match and localisation in one call (imatch_match_localize): kNN of the frame's set `q` against the
+        map's set `t` (both from sift_extract*), ratio test, and -- with more than `min_good` survivors,
+        position_finder.py:316 -- the homography of the matched keypoints. -> (good_q, good_t, good_dist, H or None,
+        mask or None): what knn2_dev + ratio_dev + homography give, bit for bit, without the host round trip in between."""
+        nq = len(q)
+        gq = np.empty(max(nq, 1), np.int32)
+        gt = np.empty(max(nq, 1), np.int32)
+        gd = np.empty(max(nq, 1), np.float32)
+        mask = np.zeros((max(nq, 1), 1), np.uint8)
+        H = np.zeros((3, 3), np.float64)
+        n = c_i64(0)
+        found = ctypes.c_int(0)
+        with self.lock:
+            self._check(self.lib.imatch_match_localize(self._h, q._h, t._h, float(ratio), int(min_good), float(thr),
+                                                       ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(gq, c_i32p),
+                                                       _ptr(gt, c_i32p), _ptr(gd, c_f32p), ctypes.byref(n),
+                                                       H.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ptr(mask, c_u8p),
+                                                       ctypes.byref(found)))
+        g = n.value
+        if not found.value:
+            return gq[:g], gt[:g], gd[:g], None, None
+        return gq[:g], gt[:g], gd[:g], H, mask[:g]
+
+    def match_localize_mismatches(self):
+        return int(self.lib.imatch_match_localize_debug_mismatches(self._h))
 
     def ratio_batch_dev(self, out4_ptr, offsets, ratio):
         """Ratio test on the rows of a batch: -> (good_q local to each segment, good_t, good_d, good_offsets)."""

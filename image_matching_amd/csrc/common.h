@@ -34,6 +34,7 @@ struct imatch_ctx {
     int* knn_gthr;
     size_t knn_gthr_words;
     int knn_gthr_armed;
+    int tail_mismatches;   // imatch_match_localize: calls whose device-side Hartley transforms were not the host's (expected: 0)
     int knnf_last_path;    // the float kNN's last call: 0 exhaustive kernel, 1 filter + refinement, 2 filter tried, then exhaustive (imatch_knn2_f32_debug_last_path)
     // SIFT pyramid arena of the last extraction (kept for reuse by the next frame of the same size)
     struct imatch_sift_state* sift;
@@ -59,6 +60,8 @@ struct imatch_features {
     int* norm;        // int32 [n_pad] squared L2 norms of the SHIFTED rows (the kNN works on differences only), device
     int* tneg;        // int32 [n_pad] = -norm: the MFMA accumulator starts at tneg >> 1; norm + n_pad
     int* flag;        // device int: 1 if some value was not an integer in 0..255
+    float* xy;        // device float [n_pad][2]: the keypoints' coordinates, written by the descriptor kernel (has_xy), else unset
+    int has_xy;
     int integral;     // host copy of !flag, valid after creation
     // sets produced by imatch_sift_extract also carry:
     float* kp;        // host [n][7] keypoint records (final order), or null

@@ -93,9 +93,10 @@ struct HomoSeg {
 
 __global__ void __launch_bounds__(256)
 homography_score_kernel(const double* __restrict__ pts_all, const float* __restrict__ fpts_all, HomoSeg hs,
-                        unsigned long long* __restrict__ best) {
+                        unsigned long long* __restrict__ best, const int* __restrict__ n_dev) {
     const int b = blockIdx.y;
-    const int n = hs.seg.off[b + 1] - hs.seg.off[b];
+    // n_dev: a single problem whose size the host has not seen yet (imatch_match_localize); 0 = nothing to score
+    const int n = n_dev ? *n_dev : hs.seg.off[b + 1] - hs.seg.off[b];
     if (n < 4) return;
     const double* pts = pts_all + 4 * (size_t)hs.seg.off[b];
     const float* fpts = fpts_all + 4 * (size_t)hs.seg.off[b];
@@ -295,6 +296,48 @@ static bool refit(const double* __restrict__ P, int n, double tau2, double h8[8]
     return true;
 }
 
+// Everything after the scoring of one problem of n >= 4 correspondences: the winner is built again from its index (the
+// code the device ran), refit, taken back to pixel coordinates; mask = forward error <= thr as OpenCV's. P: the normalised
+// points [4][n], sp / dp: the pixel coordinates [n][2], ts / td: the two Hartley transforms (scale, centre x, centre y).
+static void finish_problem(const double* P, const float* sp, const float* dp, int n, const double* ts, const double* td,
+                           double tau, unsigned long long key, uint64_t seed, double thr, double* Ho, uint8_t* mask, int* found) {
+    if (key == 0) return;  // no non-degenerate sample
+    const uint32_t h = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+    double Hb[9];
+    if (!hypothesis(P, n, seed, h, Hb) || fabs(Hb[8]) <= 1e-9) return;
+    double h8[8];
+    for (int k = 0; k < 8; ++k) h8[k] = Hb[k] / Hb[8];
+    std::vector<double> scratch(6 * (size_t)n);
+    if (!refit(P, n, tau * tau, h8, scratch.data())) return;
+    const double Hn[9] = {h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7], 1.0};
+    const double TS[9] = {ts[0], 0, -ts[0] * ts[1], 0, ts[0], -ts[0] * ts[2], 0, 0, 1};
+    const double TDi[9] = {1.0 / td[0], 0, td[1], 0, 1.0 / td[0], td[2], 0, 0, 1};
+    double t[9], H[9];
+    mul3(Hn, TS, t);
+    mul3(TDi, t, H);
+    if (fabs(H[8]) < 1e-12) return;
+    for (int k = 0; k < 9; ++k) Ho[k] = H[k] / H[8];
+    if (mask)
+        for (int i = 0; i < n; ++i) {
+            const double x = sp[2 * i], y = sp[2 * i + 1];
+            const double ww = Ho[6] * x + Ho[7] * y + 1.0;
+            const double ex = (Ho[0] * x + Ho[1] * y + Ho[2]) / ww - dp[2 * i];
+            const double ey = (Ho[3] * x + Ho[4] * y + Ho[5]) / ww - dp[2 * i + 1];
+            mask[i] = (ex * ex + ey * ey <= thr * thr) ? 1 : 0;
+        }
+    *found = 1;
+}
+
+// normalised points of one problem: P [4][n] doubles (sx, sy, dx, dy), F the same rounded to f32
+static void normalise_points(const float* sp, const float* dp, int n, const double* ts, const double* td, double* P, float* F) {
+    for (int i = 0; i < n; ++i) {
+        P[i] = ts[0] * (sp[2 * i] - ts[1]); P[n + i] = ts[0] * (sp[2 * i + 1] - ts[2]);
+        P[2 * n + i] = td[0] * (dp[2 * i] - td[1]); P[3 * n + i] = td[0] * (dp[2 * i + 1] - td[2]);
+    }
+    if (F)
+        for (int i = 0; i < 4 * n; ++i) F[i] = (float)P[i];
+}
+
 // Shared by the single and the batched entry point: segment b's correspondences are src/dst rows
 // [off[b], off[b+1]).
 static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, const imatch_segtab& seg, double thr,
@@ -335,13 +378,7 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
         double* td = &Td[3 * b];
         hartley(sp, n, ts);
         hartley(dp, n, td);
-        double* P = Pall + 4 * (size_t)seg.off[b];
-        float* F = Fall + 4 * (size_t)seg.off[b];
-        for (int i = 0; i < n; ++i) {
-            P[i] = ts[0] * (sp[2 * i] - ts[1]); P[n + i] = ts[0] * (sp[2 * i + 1] - ts[2]);
-            P[2 * n + i] = td[0] * (dp[2 * i] - td[1]); P[3 * n + i] = td[0] * (dp[2 * i + 1] - td[2]);
-        }
-        for (int i = 0; i < 4 * n; ++i) F[i] = (float)P[i];
+        normalise_points(sp, dp, n, ts, td, Pall + 4 * (size_t)seg.off[b], Fall + 4 * (size_t)seg.off[b]);
         tau[b] = fmax(thr, HOMO_TAU_FLOOR) * td[0];
         h_itau2[b] = (float)(1.0 / (tau[b] * tau[b]));
     }
@@ -367,45 +404,17 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
                            (const double*)dev, (const float*)(dev + dbytes), hs, d_best);
     else
         hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / (nseg >= 8 ? 256 : 64), nseg), dim3(nseg >= 8 ? 256 : 64), 0,
-                           ctx->stream, (const double*)dev, (const float*)(dev + dbytes), hs, d_best);
+                           ctx->stream, (const double*)dev, (const float*)(dev + dbytes), hs, d_best, (const int*)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     (void)imatch_stage_end(ctx, IMATCH_STAGE_HOMOGRAPHY, ctx->stream);
     HIP_TRY(ctx, hipMemcpyAsync(h_key, d_best, kbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     auto finish = [&](int b) {
         const int n = seg.off[b + 1] - seg.off[b];
-        const unsigned long long key = h_key[b];
-        if (n < 4 || key == 0) return;  // no non-degenerate sample
-        const double* P = Pall + 4 * (size_t)seg.off[b];
-        const float* sp = src + 2 * (size_t)seg.off[b];
-        const float* dp = dst + 2 * (size_t)seg.off[b];
-        const double* ts = &Ts[3 * b];
-        const double* td = &Td[3 * b];
-        const uint32_t h = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
-        double Hb[9];
-        if (!hypothesis(P, n, seeds[b], h, Hb) || fabs(Hb[8]) <= 1e-9) return;
-        double h8[8];
-        for (int k = 0; k < 8; ++k) h8[k] = Hb[k] / Hb[8];
-        std::vector<double> scratch(6 * (size_t)n);
-        if (!refit(P, n, tau[b] * tau[b], h8, scratch.data())) return;
-        const double Hn[9] = {h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7], 1.0};
-        const double TS[9] = {ts[0], 0, -ts[0] * ts[1], 0, ts[0], -ts[0] * ts[2], 0, 0, 1};
-        const double TDi[9] = {1.0 / td[0], 0, td[1], 0, 1.0 / td[0], td[2], 0, 0, 1};
-        double t[9], H[9];
-        mul3(Hn, TS, t);
-        mul3(TDi, t, H);
-        if (fabs(H[8]) < 1e-12) return;
-        double* Ho = H_out + 9 * (size_t)b;
-        for (int k = 0; k < 9; ++k) Ho[k] = H[k] / H[8];
-        if (mask)
-            for (int i = 0; i < n; ++i) {
-                const double x = sp[2 * i], y = sp[2 * i + 1];
-                const double ww = Ho[6] * x + Ho[7] * y + 1.0;
-                const double ex = (Ho[0] * x + Ho[1] * y + Ho[2]) / ww - dp[2 * i];
-                const double ey = (Ho[3] * x + Ho[4] * y + Ho[5]) / ww - dp[2 * i + 1];
-                mask[seg.off[b] + i] = (ex * ex + ey * ey <= thr * thr) ? 1 : 0;
-            }
-        found[b] = 1;
+        if (n < 4) return;
+        finish_problem(Pall + 4 * (size_t)seg.off[b], src + 2 * (size_t)seg.off[b], dst + 2 * (size_t)seg.off[b], n, &Ts[3 * b],
+                       &Td[3 * b], tau[b], h_key[b], seeds[b], thr, H_out + 9 * (size_t)b, mask ? mask + seg.off[b] : nullptr,
+                       found + b);
     };
     if (nseg >= 4) {  // the problems are independent: refit them on the context's host workers
         imatch_parallel_for(ctx, nseg, [&](int b) { finish(b); });
@@ -414,6 +423,225 @@ static int homography_run(imatch_ctx* ctx, const float* src, const float* dst, c
     }
     return IMATCH_OK;
 }
+
+// ---- one frame's match and localisation without a host round trip in the middle (imatch_match_localize) ---------------
+// The per-frame calls hand the ratio test's survivors to the host, which looks up their coordinates, normalises them and
+// sends them back for the scoring: a copy, a wake-up, host work and another copy, 40 us of a 0.58 ms frame in which the GPU
+// waits. Here one workgroup does all of it where the kNN's result lies: the ratio test and the compaction in query order
+// (ratio_kernel's, knn.hip), the gather of both sides' coordinates from the sets' tables, the two Hartley transforms --
+// the centre and the mean distance are sums in index order, so one lane adds them up, the other lanes supply the square
+// roots -- and the normalised points; the scoring kernel reads the count from the device. The arithmetic is the host's
+// (hartley, normalise_points: IEEE double operations in the same order, no contraction in either build), so the points,
+// the scores and the winner are those of the separate calls; the host still checks the transforms that come back
+// against its own, bit for bit, and takes the separate path when they differ or when a list does not fit.
+#define TAIL_CAP 1024
+struct TailHdr {
+    int n_good;      // survivors of the ratio test; beyond cap nothing else is valid
+    int scored;      // 1: the points were normalised and the hypotheses scored
+    double ts[3], td[3], tau;
+    unsigned long long key;   // the scoring kernel's atomicMax word
+    unsigned long long seed;
+    float inv_tau2;
+    int n_score;     // what the scoring kernel reads: n_good, or 0
+};
+
+__global__ void __launch_bounds__(1024)
+match_tail_kernel(const int4* __restrict__ in, int nq, double ratio, const float2* __restrict__ q_xy,
+                  const float2* __restrict__ t_xy, int cap, int min_good, double thr, unsigned long long seed,
+                  TailHdr* __restrict__ hdr, int* __restrict__ gq, int* __restrict__ gt, float* __restrict__ gd,
+                  double* __restrict__ P, float* __restrict__ F) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    __shared__ float2 sxy[TAIL_CAP], dxy[TAIL_CAP];
+    __shared__ double term[2][TAIL_CAP];
+    __shared__ double T[2][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += 1024) {   // ratio_kernel's loop, one segment
+        const int q = q0 + threadIdx.x;
+        bool good = false;
+        int4 e = make_int4(0, -1, 0, -1);
+        float d1 = 0.f;
+        if (q < nq) {
+            e = in[q];
+            if (e.y >= 0 && e.w >= 0) {
+                d1 = sqrtf((float)e.x);
+                const float d2 = sqrtf((float)e.z);
+                good = (double)d1 < ratio * (double)d2;
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(good);
+        const int within = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (good && off + within < cap) {
+            gq[off + within] = q;
+            gt[off + within] = e.y;
+            gd[off + within] = d1;
+            sxy[off + within] = q_xy[q];
+            dxy[off + within] = t_xy[e.y];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wsum[w];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+    const int n = base_s;
+    const bool go = n > min_good && n >= 4 && n <= cap;
+    if (threadIdx.x == 0) {
+        hdr->n_good = n;
+        hdr->scored = go ? 1 : 0;
+        hdr->key = 0ull;
+        hdr->seed = seed;
+        if (!go) hdr->n_score = 0;
+    }
+    if (!go) return;
+    // hartley(): centre = the coordinates' sum in index order / n
+    if (lane == 0 && wave < 2) {
+        const float2* p = wave == 0 ? sxy : dxy;
+        double cx = 0, cy = 0;
+        for (int i = 0; i < n; ++i) { cx += p[i].x; cy += p[i].y; }
+        T[wave][1] = cx / n;
+        T[wave][2] = cy / n;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * n; i += 1024) {
+        const int side = i >= n, k = side ? i - n : i;
+        const float2 p = side ? dxy[k] : sxy[k];
+        const double cx = T[side][1], cy = T[side][2];
+        term[side][k] = sqrt((p.x - cx) * (p.x - cx) + (p.y - cy) * (p.y - cy));
+    }
+    __syncthreads();
+    if (lane == 0 && wave < 2) {
+        double md = 0;
+        for (int i = 0; i < n; ++i) md += term[wave][i];
+        md /= n;
+        T[wave][0] = md > 1e-12 ? sqrt(2.0) / md : 1.0;
+    }
+    __syncthreads();
+    const double ts0 = T[0][0], ts1 = T[0][1], ts2 = T[0][2], td0 = T[1][0], td1 = T[1][1], td2 = T[1][2];
+    for (int i = threadIdx.x; i < n; i += 1024) {   // normalise_points()
+        const double a = ts0 * (sxy[i].x - ts1), b = ts0 * (sxy[i].y - ts2);
+        const double c = td0 * (dxy[i].x - td1), d = td0 * (dxy[i].y - td2);
+        P[i] = a; P[n + i] = b; P[2 * n + i] = c; P[3 * n + i] = d;
+        F[i] = (float)a; F[n + i] = (float)b; F[2 * n + i] = (float)c; F[3 * n + i] = (float)d;
+    }
+    if (threadIdx.x == 0) {
+        const double tau = fmax(thr, HOMO_TAU_FLOOR) * td0;
+        hdr->ts[0] = ts0; hdr->ts[1] = ts1; hdr->ts[2] = ts2;
+        hdr->td[0] = td0; hdr->td[1] = td1; hdr->td[2] = td2;
+        hdr->tau = tau;
+        hdr->inv_tau2 = (float)(1.0 / (tau * tau));
+        hdr->n_score = n;
+    }
+}
+
+static int match_localize_separately(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, const int32_t* out4,
+                                     double ratio, int min_good, double thr, uint64_t seed, int32_t* good_q, int32_t* good_t,
+                                     float* good_d, int64_t* n_good, double* H_out, uint8_t* mask, int* found) {
+    int rc = imatch_ratio_dev(ctx, out4, q->n, ratio, good_q, good_t, good_d, n_good);
+    if (rc) return rc;
+    const int n = (int)*n_good;
+    if (n <= min_good || n < 4) return IMATCH_OK;
+    std::vector<float> src(2 * (size_t)n), dst(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        src[2 * i] = q->kp[7 * (size_t)good_q[i]]; src[2 * i + 1] = q->kp[7 * (size_t)good_q[i] + 1];
+        dst[2 * i] = t->kp[7 * (size_t)good_t[i]]; dst[2 * i + 1] = t->kp[7 * (size_t)good_t[i] + 1];
+    }
+    return imatch_homography(ctx, src.data(), dst.data(), n, thr, seed, H_out, mask, found);
+}
+
+extern "C" int imatch_match_localize(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, double ratio,
+                                     int min_good, double thr, uint64_t seed, int32_t* good_q, int32_t* good_t, float* good_d,
+                                     int64_t* n_good, double* H_out, uint8_t* mask, int* found) {
+    if (!ctx || !q || !t || !n_good || !H_out || !found || (q->n > 0 && (!good_q || !good_t || !good_d)))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "null argument");
+    if (!q->has_xy || !t->has_xy || (q->n > 0 && !q->kp) || (t->n > 0 && !t->kp))
+        return imatch_set_err(ctx, IMATCH_EINVAL, "both descriptor sets must come from imatch_sift_extract* (they carry their "
+                                                  "keypoints' coordinates); use imatch_knn2_dev / imatch_ratio_dev / imatch_homography");
+    if (q->n > INT_MAX / 2) return imatch_set_err(ctx, IMATCH_ESIZE, "too many queries");
+    *n_good = 0;
+    *found = 0;
+    if (q->n == 0) return IMATCH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    static const int cap_env = getenv("IMATCH_TAIL_CAP") ? atoi(getenv("IMATCH_TAIL_CAP")) : TAIL_CAP;   // tests: force the overflow path
+    const int cap = std::max(4, std::min(cap_env, TAIL_CAP));
+    const int nq = (int)q->n;
+    // device block: kNN result, header, lists, points
+    const size_t o_out4 = 0, o_hdr = o_out4 + (((size_t)nq * 16 + 255) & ~(size_t)255), o_gq = o_hdr + 256,
+                 o_gt = o_gq + 4 * (size_t)cap, o_gd = o_gt + 4 * (size_t)cap, o_P = (o_gd + 4 * (size_t)cap + 255) & ~(size_t)255,
+                 o_F = o_P + 32 * (size_t)cap, total = o_F + 16 * (size_t)cap;
+    struct Block {   // back to the pool on every way out
+        imatch_ctx* c;
+        char* p;
+        ~Block() { if (p) imatch_pool_free(c, p); }
+    } blk{ctx, (char*)imatch_pool_alloc(ctx, total)};
+    if (!blk.p) return imatch_set_err(ctx, IMATCH_ENOMEM, "match block for %d queries", nq);
+    int32_t* out4 = (int32_t*)(blk.p + o_out4);
+    TailHdr* d_hdr = (TailHdr*)(blk.p + o_hdr);
+    const size_t back = 256 + 12 * (size_t)cap;   // header + the three lists, contiguous
+    int rc = imatch_hs_reserve(ctx, back);
+    if (rc) return rc;
+    rc = imatch_knn2_dev(ctx, q, t, 0, out4);
+    if (rc) return rc;
+    (void)imatch_stage_begin(ctx, IMATCH_STAGE_RATIO, ctx->stream);
+    hipLaunchKernelGGL(match_tail_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int4*)out4, nq, ratio, (const float2*)q->xy,
+                       (const float2*)t->xy, cap, min_good, thr, (unsigned long long)seed, d_hdr, (int*)(blk.p + o_gq),
+                       (int*)(blk.p + o_gt), (float*)(blk.p + o_gd), (double*)(blk.p + o_P), (float*)(blk.p + o_F));
+    HIP_TRY(ctx, hipGetLastError());
+    (void)imatch_stage_end(ctx, IMATCH_STAGE_RATIO, ctx->stream);
+    HomoSeg hs;
+    memset(&hs, 0, sizeof(hs));
+    hs.seg.n = 1;
+    hs.seeds = &d_hdr->seed;
+    hs.inv_tau2 = &d_hdr->inv_tau2;
+    (void)imatch_stage_begin(ctx, IMATCH_STAGE_HOMOGRAPHY, ctx->stream);
+    hipLaunchKernelGGL(homography_score_kernel, dim3(HOMO_HYPOTHESES / 64, 1), dim3(64), 0, ctx->stream,
+                       (const double*)(blk.p + o_P), (const float*)(blk.p + o_F), hs, &d_hdr->key, (const int*)&d_hdr->n_score);
+    HIP_TRY(ctx, hipGetLastError());
+    (void)imatch_stage_end(ctx, IMATCH_STAGE_HOMOGRAPHY, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hs, d_hdr, back, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const TailHdr hdr = *(const TailHdr*)ctx->hs;
+    const int n = hdr.n_good;
+    if (n > cap)   // the lists did not fit the block: the per-frame calls, on the kNN result that is still here
+        return match_localize_separately(ctx, q, t, out4, ratio, min_good, thr, seed, good_q, good_t, good_d, n_good, H_out, mask, found);
+    memcpy(good_q, (char*)ctx->hs + 256, 4 * (size_t)n);
+    memcpy(good_t, (char*)ctx->hs + 256 + 4 * (size_t)cap, 4 * (size_t)n);
+    memcpy(good_d, (char*)ctx->hs + 256 + 8 * (size_t)cap, 4 * (size_t)n);
+    *n_good = n;
+    if (mask && n > 0) memset(mask, 0, (size_t)n);
+    if (!hdr.scored) return IMATCH_OK;   // too few matches for a homography (position_finder.py:316)
+    // the host's own transforms: the device's must be these, bit for bit
+    std::vector<float> src(2 * (size_t)n), dst(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (good_q[i] < 0 || good_q[i] >= q->n || good_t[i] < 0 || good_t[i] >= t->n)
+            return imatch_set_err(ctx, IMATCH_EHIP, "match %d of %d names rows %d / %d", i, n, good_q[i], good_t[i]);
+        src[2 * i] = q->kp[7 * (size_t)good_q[i]]; src[2 * i + 1] = q->kp[7 * (size_t)good_q[i] + 1];
+        dst[2 * i] = t->kp[7 * (size_t)good_t[i]]; dst[2 * i + 1] = t->kp[7 * (size_t)good_t[i] + 1];
+    }
+    double ts[3], td[3];
+    hartley(src.data(), n, ts);
+    hartley(dst.data(), n, td);
+    const double tau = fmax(thr, HOMO_TAU_FLOOR) * td[0];
+    static const int force_env = getenv("IMATCH_TAIL_MISMATCH") ? atoi(getenv("IMATCH_TAIL_MISMATCH")) : 0;   // tests: the mismatch path
+    if (force_env || memcmp(ts, hdr.ts, sizeof(ts)) || memcmp(td, hdr.td, sizeof(td)) || memcmp(&tau, &hdr.tau, sizeof(tau))) {
+        ctx->tail_mismatches++;
+        return imatch_homography(ctx, src.data(), dst.data(), n, thr, seed, H_out, mask, found);
+    }
+    std::vector<double> P(4 * (size_t)n);
+    normalise_points(src.data(), dst.data(), n, ts, td, P.data(), nullptr);
+    finish_problem(P.data(), src.data(), dst.data(), n, ts, td, tau, hdr.key, seed, thr, H_out, mask, found);
+    return IMATCH_OK;
+}
+
+extern "C" int imatch_match_localize_debug_mismatches(imatch_ctx* ctx) { return ctx ? ctx->tail_mismatches : 0; }
 
 extern "C" int imatch_homography(imatch_ctx* ctx, const float* src, const float* dst, int n, double thr, uint64_t seed,
                                  double* H_out, uint8_t* mask, int* found) {

@@ -626,8 +626,9 @@ int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out) {
     f->n = n;
     f->n_pad = ((n + IMATCH_ROW_PAD - 1) / IMATCH_ROW_PAD) * IMATCH_ROW_PAD;
     if (f->n_pad == 0) f->n_pad = IMATCH_ROW_PAD;
-    // one block: int8 rows, then norm + tneg (int32 each), then the integrality flag
-    f->desc = (int8_t*)imatch_pool_alloc(ctx, (size_t)f->n_pad * (128 + 8) + 256);
+    // one block: int8 rows, then norm + tneg (int32 each), the integrality flag, and room for the keypoints' (x, y) of
+    // sets made by an extraction (has_xy; imatch_match_localize gathers matched coordinates on the device)
+    f->desc = (int8_t*)imatch_pool_alloc(ctx, (size_t)f->n_pad * (128 + 8 + 8) + 256);
     if (!f->desc) {
         free(f);
         return imatch_set_err(ctx, IMATCH_ENOMEM, "device alloc for %lld descriptors", (long long)n);
@@ -635,6 +636,7 @@ int imatch_features_alloc(imatch_ctx* ctx, int64_t n, imatch_features** out) {
     f->norm = (int*)((char*)f->desc + (size_t)f->n_pad * 128);
     f->flag = (int*)((char*)f->desc + (size_t)f->n_pad * (128 + 8));
     f->tneg = f->norm + f->n_pad;
+    f->xy = (float*)((char*)f->desc + (size_t)f->n_pad * (128 + 8) + 256);
     *out = f;
     return IMATCH_OK;
 }

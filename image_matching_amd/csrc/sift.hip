@@ -1108,7 +1108,8 @@ orient_kernel(PyrTable T, const RefinedKp* __restrict__ ref, const int* __restri
 template <int WPK>
 __global__ void __launch_bounds__(256)
 describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first_octave, int8_t* __restrict__ rows_i8,
-                int* __restrict__ norm, int* __restrict__ tneg, size_t zs, const int* __restrict__ n_dev) {
+                int* __restrict__ norm, int* __restrict__ tneg, size_t zs, const int* __restrict__ n_dev,
+                float2* __restrict__ xy) {
     const size_t zo = (size_t)blockIdx.z * zs;
     kps = ZP(kps);
     int n_kp = seg.off[blockIdx.z + 1] - seg.off[blockIdx.z];
@@ -1312,6 +1313,8 @@ describe_kernel(PyrTable T, const KpRec* __restrict__ kps, SegTab seg, int first
         if (lane == 0) {
             norm[row] = s2;
             tneg[row] = -s2;
+            const KpRec k2 = kps[id];
+            xy[row] = make_float2(k2.x, k2.y);   // the set's coordinate table (imatch_match_localize)
         }
     }
 }
@@ -2079,7 +2082,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             seg1.off[1] = n_sort;
             (void)imatch_stage_begin(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
             hipLaunchKernelGGL(describe_kernel<4>, dim3(n_sort, 1, 1), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted, seg1,
-                               first_octave, spec.f->desc, spec.f->norm, spec.f->tneg, zs, (const int*)(d_cnt + 3));
+                               first_octave, spec.f->desc, spec.f->norm, spec.f->tneg, zs, (const int*)(d_cnt + 3), (float2*)spec.f->xy);
             HIP_TRY(ctx, hipGetLastError());
             (void)imatch_stage_end(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
             rc = imatch_features_pad_counted_dev(ctx, spec.f, d_cnt + 3);
@@ -2262,13 +2265,13 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             (void)imatch_stage_begin(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
             if (wpk == 4)
                 hipLaunchKernelGGL(describe_kernel<4>, dim3(max_k, 1, batch), dim3(256), 0, ctx->stream, T, (const KpRec*)d_sorted,
-                                   seg, first_octave, f->desc, f->norm, f->tneg, zs, (const int*)nullptr);
+                                   seg, first_octave, f->desc, f->norm, f->tneg, zs, (const int*)nullptr, (float2*)f->xy);
             else if (wpk == 2)
                 hipLaunchKernelGGL(describe_kernel<2>, dim3((max_k + 1) / 2, 1, batch), dim3(256), 0, ctx->stream, T,
-                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs, (const int*)nullptr);
+                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs, (const int*)nullptr, (float2*)f->xy);
             else
                 hipLaunchKernelGGL(describe_kernel<1>, dim3((max_k + 3) / 4, 1, batch), dim3(256), 0, ctx->stream, T,
-                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs, (const int*)nullptr);
+                                   (const KpRec*)d_sorted, seg, first_octave, f->desc, f->norm, f->tneg, zs, (const int*)nullptr, (float2*)f->xy);
             HIP_TRY(ctx, hipGetLastError());
             (void)imatch_stage_end(ctx, IMATCH_STAGE_DESCRIBE, ctx->stream);
         }
@@ -2287,6 +2290,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
         if (batch >= 4) imatch_parallel_for(ctx, batch, fill_table);
         else
             for (int b = 0; b < batch; ++b) fill_table(b);
+        f->has_xy = 1;   // describe_kernel wrote the coordinate table beside the rows
         *out = f;
         DBG_STEP("leave");
         return IMATCH_OK;

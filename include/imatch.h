@@ -315,6 +315,22 @@ int imatch_homography(imatch_ctx* ctx, const float* src, const float* dst, int n
 int imatch_homography_batch(imatch_ctx* ctx, const float* src, const float* dst, const int64_t* offsets,
                             int n_seg, double thr, const uint64_t* seeds, double* H, uint8_t* mask,
                             int* found);
+/* One frame's match and localisation in one call: what position_finder.py:294-318 does with a frame's descriptors
+ * (find_matches, MF:175-197; `if len(good) > 10`; find_keypoints_transform, MF:224-236) = imatch_knn2_dev +
+ * imatch_ratio_dev + the lookup of the matched keypoints' coordinates + imatch_homography, without the host round trip
+ * between the ratio test and the hypothesis scoring (one workgroup tests, compacts, gathers and normalises where the
+ * kNN's result lies; the scoring kernel reads the count on the device). Both sets must come from imatch_sift_extract*
+ * on this context (they carry their keypoints' coordinates, on the host and on the device). good_q / good_t / good_dist
+ * hold imatch_features_count(q) entries; *n_good survivors are written. A homography is looked for when
+ * *n_good > min_good (and >= 4); H, mask (may be null, *n_good bytes) and *found as imatch_homography's. Every output
+ * equals the separate calls' bit for bit (more than 1024 survivors, or device-side transforms that are not the host's,
+ * take those calls internally). */
+int imatch_match_localize(imatch_ctx* ctx, const imatch_features* q, const imatch_features* t, double ratio,
+                          int min_good, double thr, uint64_t seed, int32_t* good_q, int32_t* good_t,
+                          float* good_dist, int64_t* n_good, double* H, uint8_t* mask, int* found);
+/* test hook: calls of imatch_match_localize on this context whose device-side Hartley transforms differed from the
+ * host's (they then went through imatch_homography; expected to stay 0) */
+int imatch_match_localize_debug_mismatches(imatch_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,17 @@ for it in range(reps + 5):
     t0 = time.perf_counter()
     f = ctx.sift_extract_dev(fr.data_ptr(), 480, 640, 640, params)
     t1 = time.perf_counter()
+    if os.environ.get("FS_ONE_CALL"):
+        gq, gt, gd, H, _ = ctx.match_localize(f, f_map, 0.7, 10, 0.1, seed=it)
+        f.free()
+        t5 = time.perf_counter()
+        if it >= 5:
+            wall += t5 - t0
+            phases += np.array([t1 - t0, t5 - t1, 0, 0, 0])
+            if prof:
+                for k, v in ctx.stage_times().items():
+                    acc[k] = acc.get(k, 0.0) + v
+        continue
     ctx.knn2_dev(f, f_map, out4.data_ptr())
     gq, gt, gd = ctx.ratio_dev(out4.data_ptr(), len(f), 0.7)
     if os.environ.get("FS_SYNC"):
