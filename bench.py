@@ -187,14 +187,24 @@ def akaze_extra(ctx, map_img, ratio):
             return len(kp), H is not None
         for i, f in enumerate(frames[:2]):
             one(f, i)
-        t0 = time.perf_counter()
-        reps = 3
-        for r in range(reps):
-            for i, f in enumerate(frames):
-                n, ok = one(f, i)
-                n_kp += n
-                found += ok
-        ms = (time.perf_counter() - t0) / (reps * len(frames)) * 1e3
+        # as for single_frame: the collector off (a generational collection over this process's objects is tens of
+        # milliseconds) and the library's stage events off while timing
+        import gc
+        gc.collect()
+        gc.disable()
+        ctx.set_profiling(False)
+        try:
+            t0 = time.perf_counter()
+            reps = 5
+            for r in range(reps):
+                for i, f in enumerate(frames):
+                    n, ok = one(f, i)
+                    n_kp += n
+                    found += ok
+            ms = (time.perf_counter() - t0) / (reps * len(frames)) * 1e3
+        finally:
+            ctx.set_profiling(True)
+            gc.enable()
         return {"detector": "AKAZE(DESCRIPTOR_KAZE, 0.0005, 4, 5, PM_G2), the call of match_finder.py:210-211",
                 "ms_per_frame": ms, "frames_per_s": 1e3 / ms, "keypoints_per_frame": n_kp / (reps * len(frames)),
                 "crop": "2048x2048, %d keypoints, extracted in %.1f ms" % (len(ckp), t_crop * 1e3),
