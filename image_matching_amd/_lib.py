@@ -116,6 +116,7 @@ SIGNATURES = {
     "imatch_features_download": (ctypes.c_int, [c_vp, c_f32p, c_f32p]),
     "imatch_features_keypoints_xy": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, c_f32p]),
     "imatch_features_image": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int]),
+    "imatch_features_set_keypoints": (ctypes.c_int, [c_vp, c_f32p]),
     "imatch_sift_debug_layer": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
                                                ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "imatch_sift_debug_octaves": (ctypes.c_int, [c_vp]),
@@ -224,6 +225,15 @@ class Features:
         if rc != 0:
             raise ImatchError("imatch error %d: keypoint rows out of range or a set without keypoints" % rc)
         return out
+
+    def set_keypoints(self, kp):
+        """Keypoint records float32 [n,7] (as `download` returns them) for a set made from descriptor rows alone, e.g. a
+        map database read from disk: afterwards Context.match_localize takes the set."""
+        kp = np.ascontiguousarray(kp, dtype=np.float32)
+        if kp.shape != (self.n, 7):
+            raise ValueError("keypoint table must be [%d, 7]" % self.n)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.imatch_features_set_keypoints(self._h, _ptr(kp, c_f32p)))
 
     def desc_u8_dev(self, out_ptr):
         with self.ctx.lock:

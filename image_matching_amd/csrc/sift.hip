@@ -2326,6 +2326,35 @@ int imatch_features_keypoints_xy(const imatch_features* f, const int64_t* rows, 
     return IMATCH_OK;
 }
 
+// keypoint records for a set that was made from descriptor rows alone (a map database loaded from disk): the host table
+// and the device-side coordinate table, as an extraction leaves them -- imatch_match_localize then takes the set
+int imatch_features_set_keypoints(imatch_features* f, const float* kp) {
+    if (!f) return IMATCH_EINVAL;
+    imatch_ctx* ctx = f->ctx;
+    if (f->n > 0 && !kp) return imatch_set_err(ctx, IMATCH_EINVAL, "null keypoint table");
+    if (f->n == 0) { f->has_xy = 1; return IMATCH_OK; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float* table = (float*)malloc(sizeof(float) * 7 * (size_t)f->n);
+    if (!table) return imatch_set_err(ctx, IMATCH_ENOMEM, "keypoint table");
+    memcpy(table, kp, sizeof(float) * 7 * (size_t)f->n);
+    // coordinates up through the pinned block, a slice at a time (a 20 M-row map's are 160 MB)
+    const size_t slice = (size_t)1 << 20;
+    int rc = imatch_hs_reserve(ctx, std::min((size_t)f->n, slice) * 8);
+    if (rc) { free(table); return rc; }
+    for (size_t lo = 0; lo < (size_t)f->n; lo += slice) {
+        const size_t cnt = std::min(slice, (size_t)f->n - lo);
+        float* h = (float*)ctx->hs;
+        for (size_t i = 0; i < cnt; ++i) { h[2 * i] = table[7 * (lo + i)]; h[2 * i + 1] = table[7 * (lo + i) + 1]; }
+        hipError_t e = hipMemcpyAsync(f->xy + 2 * lo, h, cnt * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { free(table); return imatch_set_err(ctx, IMATCH_EHIP, "coordinate upload: %s", hipGetErrorString(e)); }
+    }
+    free(f->kp);
+    f->kp = table;
+    f->has_xy = 1;
+    return IMATCH_OK;
+}
+
 int imatch_features_download(const imatch_features* f, float* kp, float* desc) {
     if (!f) return IMATCH_EINVAL;
     imatch_ctx* ctx = f->ctx;

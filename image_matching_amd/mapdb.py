@@ -144,7 +144,9 @@ class MapDB:
         if key not in self._resident:
             lo, hi = partition(len(self), world)[rank]
             rows = np.ascontiguousarray(self.desc[lo:hi])        # reads the memory-mapped range
-            self._resident[key] = (ctx.features(rows), lo)
+            f = ctx.features(rows)
+            f.set_keypoints(np.asarray(self.kp[lo:hi]))          # the range's keypoints beside its rows (match_localize)
+            self._resident[key] = (f, lo)
         return self._resident[key]
 
     def release(self):
@@ -173,9 +175,15 @@ class MapDB:
         ctx.knn2_dev(frame_features, f_map, out4.data_ptr(), lo)
         return ctx.ratio_dev(out4.data_ptr(), nq, ratio)
 
-    def locate(self, ctx, frame_features, frame_xy, ratio=0.7, thr=0.1, seed=0, min_good=10):
+    def locate(self, ctx, frame_features, frame_xy=None, ratio=0.7, thr=0.1, seed=0, min_good=10):
         """The frame's homography into FULL-MAP pixel coordinates (find_matches + find_keypoints_transform against
         the whole map instead of a crop): -> (H or None, number of good matches)."""
+        if frame_xy is None:
+            # the frame's set comes from sift_extract* and carries its keypoints: the whole tail in one library call
+            # (same survivors, same H as the calls below)
+            f_map, lo = self.to_device(ctx)
+            gq, gt, _, H, _ = ctx.match_localize(frame_features, f_map, ratio, min_good, thr, seed)
+            return H, len(gq)
         gq, gt, _ = self.match(ctx, frame_features, ratio)
         if len(gq) <= min_good:                                   # position_finder.py:316
             return None, len(gq)

@@ -186,6 +186,11 @@ int imatch_sift_extract_batch_dev(imatch_ctx* ctx, const uint8_t* img_dev, int n
  * order: sorted and de-duplicated as KeyPointsFilter::removeDuplicatedSorted leaves them);
  * desc: [K][128] f32, integer valued 0..255. Either pointer may be null. */
 int imatch_features_download(const imatch_features* f, float* kp, float* desc);
+/* Gives a set made from descriptor rows alone (imatch_features_from_*: a map database read from disk, whose keypoints
+ * the reference keeps beside the descriptors, match_finder.py:220-221) its keypoint records [n][7], as
+ * imatch_features_download returns them: the host table and the device-side coordinate table an extraction would have
+ * left, so that imatch_match_localize accepts the set. Replaces records given before. */
+int imatch_features_set_keypoints(imatch_features* f, const float* kp);
 /* (x, y) of the keypoints rows[0..n): what the reference gathers for findHomography with
  * `kp[m.queryIdx].pt` (MF:231-232), without copying the whole keypoint table. out_xy: [n][2] f32. */
 int imatch_features_keypoints_xy(const imatch_features* f, const int64_t* rows, int64_t n, float* out_xy);

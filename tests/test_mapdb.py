@@ -109,6 +109,10 @@ def test_build_matches_direct_extraction_and_sharded_build(ctx, tmp_path):
         q = np.c_[p, np.ones(len(p))] @ np.asarray(Hm).T
         return q[:, :2] / q[:, 2:]
     assert np.abs(proj(H, corners) - proj(Htrue, corners)).max() <= 1.0
+    # without the coordinates: the frame's set carries them, the resident set got the database's keypoints when it was
+    # loaded (imatch_features_set_keypoints) -- one library call (imatch_match_localize), the same H bit for bit
+    H1, n1 = back.locate(ctx, ff)
+    assert n1 == n_good and np.array_equal(H1, H)
     # resident set: a second call does not upload again, and a sharded load splits the rows contiguously
     assert back.to_device(ctx)[0] is back.to_device(ctx)[0]
     f0, lo0 = back.to_device(ctx, 0, 2)
