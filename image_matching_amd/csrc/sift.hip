@@ -2009,7 +2009,7 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             HIP_TRY(ctx, hipGetLastError());
         }
         (void)imatch_stage_end(ctx, IMATCH_STAGE_KEYPOINTS, ctx->stream);
-        // ---- A single frame sorted on the device: its descriptors are queued before the host has seen a count (behind the copies below). The
+        // ---- A single frame sorted on the device: its descriptors are queued before the host has seen a count (right behind the sort; the copies below leave on the copy stream). The
         // set is allocated for as many rows as the sort was launched for (the frame's keypoints are at most that many, or
         // the sort reports -1 and the launch does nothing), the kernels read the count where the sort left it, and the
         // host fixes the set's row count after the synchronisation. The GPU used to idle from the end of the sort to the
