@@ -5,6 +5,7 @@
 // bit-identical to the oracle.
 #include "common.h"
 #include "preproc.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -76,6 +77,68 @@ clahe_lut_kernel(const int* __restrict__ hist, int clip, float lut_scale, uint8_
     lut[blockIdx.x * 256 + i] = sat_u8((float)s[i] * lut_scale);
 }
 
+// Histogram and LUT of one tile in one workgroup, the histogram in LDS (four copies, a wave uses copy wave % 4): a camera
+// frame's CLAHE was a clear of the global histograms, the band kernel, the LUT kernel and the interpolation -- four
+// dependent launches of 2-4 us each with their gaps at the head of a 0.55 ms frame; this replaces the first three. Integer
+// counts and an integer prefix sum: the LUT is the two kernels' bit for bit. Used for tiles of at most CLAHE_FUSED_MAX_PX
+// pixels (a 1024-thread workgroup walks 16 pixels per thread there); larger tiles keep the band kernel.
+#define CLAHE_FUSED_MAX_PX 16384
+__global__ void __launch_bounds__(1024)
+clahe_tile_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, int tw, int th, int tiles_x, int clip,
+                  float lut_scale, uint8_t* __restrict__ lut, size_t src_zs, size_t zs, int* __restrict__ clear64) {
+    src += (size_t)blockIdx.z * src_zs;
+    lut += (size_t)blockIdx.z * zs;
+    if (clear64 && blockIdx.x == 0 && threadIdx.x < 64) ((int*)((char*)clear64 + (size_t)blockIdx.z * zs))[threadIdx.x] = 0;
+    __shared__ int h[4][256];
+    __shared__ int wsum[4];
+    __shared__ int total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ((int*)h)[tid] = 0;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile % tiles_x;
+    int* const mine = h[wave & 3];
+    // a wave takes a row at a time (consecutive lanes, consecutive bytes)
+    for (int y = wave; y < th; y += 16) {
+        const uint8_t* p = src + (size_t)reflect101(ty * th + y, rows) * stride;
+        for (int x = lane; x < tw; x += 64) atomicAdd(&mine[p[reflect101(tx * tw + x, cols)]], 1);
+    }
+    __syncthreads();
+    int v = 0, over = 0;
+    if (tid < 256) {
+        v = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+        if (clip > 0) {
+            over = v > clip ? v - clip : 0;
+            if (v > clip) v = clip;
+            if (over) atomicAdd(&total, over);
+        }
+    }
+    __syncthreads();
+    if (clip > 0 && tid < 256) {
+        const int clipped = total;
+        const int batch = clipped / 256;
+        const int residual = clipped - batch * 256;
+        v += batch;
+        if (residual != 0) {
+            const int step = max(256 / residual, 1);
+            if (tid % step == 0 && tid / step < residual) v += 1;
+        }
+    }
+    // inclusive prefix over the 256 bins (the first four waves): within the wave by shuffles, then the waves before
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (tid < 256 && lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (tid < 256) {
+        for (int w = 0; w < wave; ++w) incl += wsum[w];
+        lut[tile * 256 + tid] = sat_u8((float)incl * lut_scale);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 clahe_apply_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stride, int tw, int th, int tiles_x,
                    int tiles_y, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst, size_t src_zs, size_t zs) {
@@ -105,7 +168,8 @@ clahe_apply_kernel(const uint8_t* __restrict__ src, int rows, int cols, int stri
 
 int imatch_clahe_dev(imatch_ctx* ctx, const uint8_t* src_dev, int h, int w, int stride, double clip_limit, int tiles_x,
                      int tiles_y, uint8_t* dst_dev, void* scratch /* >= tiles*(1024+256) bytes */, int batch, size_t src_zs,
-                     size_t zs) {
+                     size_t zs, int* clear64, bool* cleared) {
+    if (cleared) *cleared = false;
     int eh = h, ew = w;
     if (w % tiles_x != 0 || h % tiles_y != 0) {
         eh = h + (tiles_y - h % tiles_y);
@@ -120,6 +184,17 @@ int imatch_clahe_dev(imatch_ctx* ctx, const uint8_t* src_dev, int h, int w, int 
     }
     int* hist = (int*)scratch;
     uint8_t* lut = (uint8_t*)scratch + (size_t)tiles * 1024;
+    // 0: the band kernel always; 1 (default): one workgroup per tile for single images with small tiles; 2: for batches too
+    static const int fused_env = getenv("IMATCH_CLAHE_FUSED") ? atoi(getenv("IMATCH_CLAHE_FUSED")) : 1;
+    if (total <= CLAHE_FUSED_MAX_PX && (fused_env == 2 || (fused_env == 1 && batch == 1))) {
+        hipLaunchKernelGGL(clahe_tile_kernel, dim3(tiles, 1, batch), dim3(1024), 0, ctx->stream, src_dev, h, w, stride, tw, th,
+                           tiles_x, clip, (float)255 / total, lut, src_zs, zs, clear64);
+        if (cleared) *cleared = clear64 != nullptr;
+        hipLaunchKernelGGL(clahe_apply_kernel, dim3((w + 63) / 64, (h + 3) / 4, batch), dim3(256), 0, ctx->stream, src_dev, h, w,
+                           stride, tw, th, tiles_x, tiles_y, lut, dst_dev, src_zs, zs);
+        HIP_TRY(ctx, hipGetLastError());
+        return IMATCH_OK;
+    }
     if (batch == 1) HIP_TRY(ctx, hipMemsetAsync(hist, 0, (size_t)tiles * 1024, ctx->stream));
     else HIP_TRY(ctx, hipMemset2DAsync(hist, zs, 0, (size_t)tiles * 1024, (size_t)batch, ctx->stream));
     int slices = (th + 63) / 64;

@@ -1748,17 +1748,19 @@ static int sift_extract(imatch_ctx* ctx, const uint8_t* img, int img_on_device, 
             DBG_STEP("upload queued");
             if (rcu) return rcu;
         }
+        bool cnt_cleared = false;   // the image's counter block (64 ints): cleared by the CLAHE tile kernel on its way, or here
         if (P->clahe) {
             (void)imatch_stage_begin(ctx, IMATCH_STAGE_CLAHE, ctx->stream);
             int rc = imatch_clahe_dev(ctx, d_src, h, w, src_stride, P->clahe_clip, P->clahe_tiles_x, P->clahe_tiles_y, d_clahe,
-                                      A + o_cscr, batch, src_zs, zs);
+                                      A + o_cscr, batch, src_zs, zs, d_cnt, &cnt_cleared);
             if (rc) return rc;
             (void)imatch_stage_end(ctx, IMATCH_STAGE_CLAHE, ctx->stream);
             d_src = d_clahe;
             src_stride = w;
             src_zs = zs;
         }
-        if (batch == 1) HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
+        if (cnt_cleared) {
+        } else if (batch == 1) HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 256, ctx->stream));
         else HIP_TRY(ctx, hipMemset2DAsync(d_cnt, zs, 0, 256, (size_t)batch, ctx->stream));
         { const int rcs = imatch_stage_begin(ctx, IMATCH_STAGE_SCALE_SPACE, ctx->stream); if (rcs) return rcs; }
         bool fused = false;
