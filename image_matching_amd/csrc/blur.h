@@ -318,9 +318,11 @@ static inline void blur_march_launch(hipStream_t st, const void* src, float* dst
 // bit-identical; cells of an intermediate layer that lie OUTSIDE the image are overwritten with copies of their
 // reflect-101 sources before the next blur reads them (recomputing them from mirrored inputs would visit the taps in
 // mirrored order, which is not bit-identical).
-#define B3_TW 64
-#define B3_TH 32
 #define B3_NT 512   // threads: two waves per SIMD, so that one wave's LDS round trips hide behind the other's arithmetic
+// Tile shapes: 64 x 32 where the launch fills the chip (a batch, a map, a frame's first octave: the halo is recomputed 3.5
+// times over), 32 x 16 where it does not (a frame's octaves 1-3: a few dozen to a few hundred tiles either way, and a
+// workgroup with a quarter of the cells is done sooner: 17.4 / 16.7 / 16.2 -> 15.5 / 10.0 / 9.7 us for the three launches the
+// next octave waits for; 32 x 8 and 16 x 16 are no shorter, profiles/r3_small_experiments.txt). Same cells, same chains.
 
 template <int R>
 __device__ __forceinline__ void b3_row_pass(const float* __restrict__ S, float* __restrict__ Tm, const GK<R>& gk, int r0, int r1,
@@ -351,7 +353,7 @@ __device__ __forceinline__ void b3_row_pass(const float* __restrict__ S, float* 
 }
 
 // D (in LDS) and, for cells of the workgroup's own tile inside the image, dst (+ dec) in memory
-template <int R>
+template <int R, int TW, int TH>
 __device__ __forceinline__ void b3_col_pass(const float* __restrict__ Tm, float* __restrict__ D, const GK<R>& gk, int r0, int r1,
                                             int c0, int c1, int P, float* __restrict__ dst, float* __restrict__ dec, int Y0,
                                             int X0, int ty0, int tx0, int rows, int cols) {
@@ -372,12 +374,12 @@ __device__ __forceinline__ void b3_col_pass(const float* __restrict__ Tm, float*
             for (int jj = 0; jj < 4; ++jj) acc[jj] = fmaf(kk, v[t + jj], acc[jj]);
         }
         const int gx = X0 + c;
-        const bool mine_x = gx >= tx0 && gx < tx0 + B3_TW && gx < cols;
+        const bool mine_x = gx >= tx0 && gx < tx0 + TW && gx < cols;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             D[(r + jj) * P + c] = acc[jj];
             const int gy = Y0 + r + jj;
-            if (mine_x && gy >= ty0 && gy < ty0 + B3_TH && gy < rows) {
+            if (mine_x && gy >= ty0 && gy < ty0 + TH && gy < rows) {
                 dst[(size_t)gy * cols + gx] = acc[jj];
                 if (dec && !(gy & 1) && !(gx & 1) && (gy >> 1) < (rows >> 1) && (gx >> 1) < (cols >> 1))
                     dec[(size_t)(gy >> 1) * (cols >> 1) + (gx >> 1)] = acc[jj];
@@ -405,7 +407,7 @@ __device__ __forceinline__ void b3_mirror(float* __restrict__ D, int r0, int r1,
     }
 }
 
-template <int R1, int R2, int R3>
+template <int R1, int R2, int R3, int TW, int TH>
 __global__ void __launch_bounds__(B3_NT)
 blur3_tile_kernel(const float* __restrict__ src, float* __restrict__ dst1, float* __restrict__ dst2, float* __restrict__ dst3,
                   float* __restrict__ dec, int rows, int cols, GK<R1> k1, GK<R2> k2, GK<R3> k3, int tiles_x, size_t zs) {
@@ -413,9 +415,9 @@ blur3_tile_kernel(const float* __restrict__ src, float* __restrict__ dst1, float
     constexpr int H1 = R2 + R3, H2 = R3;                     // halo of layers 1 and 2 around the tile
     constexpr int HX1 = (H1 + 3) & ~3, HX2 = (H2 + 3) & ~3;  // ... in x, rounded up to whole float4 groups
     constexpr int YB = H1 + R1, XB = HX1 + RA1;              // the tile's origin inside the buffers
-    constexpr int RB = B3_TH + 2 * YB, P = B3_TW + 2 * XB;
+    constexpr int RB = TH + 2 * YB, P = TW + 2 * XB;
     static_assert(((R2 + 3) & ~3) <= XB - HX2 && ((R3 + 3) & ~3) <= XB, "row-pass windows stay inside the buffer");
-    static_assert((B3_TH + 2 * H1) % 4 == 0 && (B3_TH + 2 * H2) % 4 == 0, "column pass walks four rows at a time");
+    static_assert((TH + 2 * H1) % 4 == 0 && (TH + 2 * H2) % 4 == 0, "column pass walks four rows at a time");
     __shared__ float4 sbuf4[RB * P / 4], tbuf4[RB * P / 4];
     float* const S = (float*)sbuf4;
     float* const Tm = (float*)tbuf4;
@@ -425,7 +427,7 @@ blur3_tile_kernel(const float* __restrict__ src, float* __restrict__ dst1, float
     dst3 = (float*)((char*)dst3 + (size_t)blockIdx.z * zs);
     if (dec) dec = (float*)((char*)dec + (size_t)blockIdx.z * zs);
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int ty0 = ty * B3_TH, tx0 = tx * B3_TW;
+    const int ty0 = ty * TH, tx0 = tx * TW;
     const int Y0 = ty0 - YB, X0 = tx0 - XB;
     // layer 0 with its halo: every buffer cell, through reflect-101 (a halo wider than a small image folds repeatedly)
     // does any region poke out of the image? (workgroup-uniform)
@@ -462,25 +464,25 @@ blur3_tile_kernel(const float* __restrict__ src, float* __restrict__ dst1, float
         }
     }
     __syncthreads();
-    b3_row_pass<R1>(S, Tm, k1, YB - H1 - R1, YB + B3_TH + H1 + R1, XB - HX1, XB + B3_TW + HX1, P);
+    b3_row_pass<R1>(S, Tm, k1, YB - H1 - R1, YB + TH + H1 + R1, XB - HX1, XB + TW + HX1, P);
     __syncthreads();
-    b3_col_pass<R1>(Tm, S, k1, YB - H1, YB + B3_TH + H1, XB - HX1, XB + B3_TW + HX1, P, dst1, nullptr, Y0, X0, ty0, tx0, rows, cols);
+    b3_col_pass<R1, TW, TH>(Tm, S, k1, YB - H1, YB + TH + H1, XB - HX1, XB + TW + HX1, P, dst1, nullptr, Y0, X0, ty0, tx0, rows, cols);
     __syncthreads();
-    if (ty0 - H1 < 0 || ty0 + B3_TH + H1 > rows || tx0 - HX1 < 0 || tx0 + B3_TW + HX1 > cols) {
-        b3_mirror(S, YB - H1, YB + B3_TH + H1, XB - HX1, XB + B3_TW + HX1, P, Y0, X0, rows, cols, R2);
+    if (ty0 - H1 < 0 || ty0 + TH + H1 > rows || tx0 - HX1 < 0 || tx0 + TW + HX1 > cols) {
+        b3_mirror(S, YB - H1, YB + TH + H1, XB - HX1, XB + TW + HX1, P, Y0, X0, rows, cols, R2);
         __syncthreads();
     }
-    b3_row_pass<R2>(S, Tm, k2, YB - H2 - R2, YB + B3_TH + H2 + R2, XB - HX2, XB + B3_TW + HX2, P);
+    b3_row_pass<R2>(S, Tm, k2, YB - H2 - R2, YB + TH + H2 + R2, XB - HX2, XB + TW + HX2, P);
     __syncthreads();
-    b3_col_pass<R2>(Tm, S, k2, YB - H2, YB + B3_TH + H2, XB - HX2, XB + B3_TW + HX2, P, dst2, nullptr, Y0, X0, ty0, tx0, rows, cols);
+    b3_col_pass<R2, TW, TH>(Tm, S, k2, YB - H2, YB + TH + H2, XB - HX2, XB + TW + HX2, P, dst2, nullptr, Y0, X0, ty0, tx0, rows, cols);
     __syncthreads();
-    if (ty0 - H2 < 0 || ty0 + B3_TH + H2 > rows || tx0 - HX2 < 0 || tx0 + B3_TW + HX2 > cols) {
-        b3_mirror(S, YB - H2, YB + B3_TH + H2, XB - HX2, XB + B3_TW + HX2, P, Y0, X0, rows, cols, R3);
+    if (ty0 - H2 < 0 || ty0 + TH + H2 > rows || tx0 - HX2 < 0 || tx0 + TW + HX2 > cols) {
+        b3_mirror(S, YB - H2, YB + TH + H2, XB - HX2, XB + TW + HX2, P, Y0, X0, rows, cols, R3);
         __syncthreads();
     }
-    b3_row_pass<R3>(S, Tm, k3, YB - R3, YB + B3_TH + R3, XB, XB + B3_TW, P);
+    b3_row_pass<R3>(S, Tm, k3, YB - R3, YB + TH + R3, XB, XB + TW, P);
     __syncthreads();
-    b3_col_pass<R3>(Tm, S, k3, YB, YB + B3_TH, XB, XB + B3_TW, P, dst3, dec, Y0, X0, ty0, tx0, rows, cols);
+    b3_col_pass<R3, TW, TH>(Tm, S, k3, YB, YB + TH, XB, XB + TW, P, dst3, dec, Y0, X0, ty0, tx0, rows, cols);
 }
 
 template <int R1, int R2, int R3>
@@ -492,7 +494,15 @@ static inline void blur3_tile_launch(hipStream_t st, const float* src, float* ds
     for (int i = 0; i < 2 * R1 + 1; ++i) g1.k[i] = k1[i];
     for (int i = 0; i < 2 * R2 + 1; ++i) g2.k[i] = k2[i];
     for (int i = 0; i < 2 * R3 + 1; ++i) g3.k[i] = k3[i];
-    const int tiles_x = (cols + B3_TW - 1) / B3_TW, tiles_y = (rows + B3_TH - 1) / B3_TH;
-    hipLaunchKernelGGL((blur3_tile_kernel<R1, R2, R3>), dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch), dim3(B3_NT), 0, st,
-                       src, dst1, dst2, dst3, dec, rows, cols, g1, g2, g3, tiles_x, zs);
+    static const int small_env = getenv("IMATCH_BLUR3_SMALL") ? atoi(getenv("IMATCH_BLUR3_SMALL")) : 1;   // 0: 64 x 32 always
+    const long long big_tiles = (long long)((cols + 63) / 64) * ((rows + 31) / 32) * batch;
+    if (small_env && big_tiles < 512) {   // the launch would leave most of the chip idle: smaller, shorter workgroups
+        const int tiles_x = (cols + 31) / 32, tiles_y = (rows + 15) / 16;
+        hipLaunchKernelGGL((blur3_tile_kernel<R1, R2, R3, 32, 16>), dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch),
+                           dim3(B3_NT), 0, st, src, dst1, dst2, dst3, dec, rows, cols, g1, g2, g3, tiles_x, zs);
+        return;
+    }
+    const int tiles_x = (cols + 63) / 64, tiles_y = (rows + 31) / 32;
+    hipLaunchKernelGGL((blur3_tile_kernel<R1, R2, R3, 64, 32>), dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch), dim3(B3_NT),
+                       0, st, src, dst1, dst2, dst3, dec, rows, cols, g1, g2, g3, tiles_x, zs);
 }
